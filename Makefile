@@ -1,0 +1,43 @@
+# Makefile -- same targets and variables as the reference's (reference Makefile:3-26:
+# EXE, all, check, clean, FINAL_STATE_FILE/AV_VELS_FILE/REF_*), building the
+# MI355X-native program: a C host (gcc) on top of the HIP library (hipcc, gfx950).
+
+EXE=d2q9-bgk
+
+CC=gcc
+HIPCC=hipcc
+CFLAGS= -std=c99 -Wall -O2
+HIPFLAGS= -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function
+PKG=advanced-hpc-lbm_amd
+LIB=$(PKG)/liblbm_mi355x.so
+
+FINAL_STATE_FILE=./final_state.dat
+AV_VELS_FILE=./av_vels.dat
+REF_FINAL_STATE_FILE=tests/golden/1024x1024.final_state.pressure.f64.npz
+REF_AV_VELS_FILE=tests/golden/1024x1024.av_vels.dat
+
+all: $(EXE)
+
+lib: $(LIB)
+
+$(LIB): $(PKG)/csrc/lbm_api.hip $(PKG)/csrc/lbm_kernels.hip.h include/lbm_mi355x.h
+	$(HIPCC) $(HIPFLAGS) -shared $< -o $@ -ldl -Wl,-rpath,/opt/rocm/lib
+
+$(EXE): $(PKG)/host/d2q9-bgk.c $(LIB) include/lbm_mi355x.h
+	$(CC) $(CFLAGS) -Iinclude $< -o $@ -L$(PKG) -llbm_mi355x -Wl,-rpath,'$$ORIGIN/$(PKG)' -Wl,-rpath,/opt/rocm/lib
+
+tools: tools/kbench
+
+tools/kbench: tools/kbench.hip $(PKG)/csrc/lbm_kernels.hip.h
+	$(HIPCC) $(HIPFLAGS) $< -o $@
+
+oracle:
+	$(MAKE) -C oracle all
+
+check:
+	python check/check_results.py --ref-av-vels-file=$(REF_AV_VELS_FILE) --ref-final-state-file=$(REF_FINAL_STATE_FILE) --av-vels-file=$(AV_VELS_FILE) --final-state-file=$(FINAL_STATE_FILE)
+
+.PHONY: all lib tools oracle check clean
+
+clean:
+	rm -f $(EXE) $(LIB) tools/kbench

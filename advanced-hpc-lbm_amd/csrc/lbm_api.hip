@@ -1,0 +1,765 @@
+// lbm_api.hip -- the C ABI of include/lbm_mi355x.h on top of the HIP kernels.
+//
+// Host-side structure (MI355X-first, nothing here mirrors the reference's
+// serial layout):
+//   * a context owns one or more ROW SLABS; each slab lives on one GPU with
+//     both lattices resident in HBM as 9 SoA planes, a byte mask, two small
+//     halo receive buffers and two packed halo send buffers per parity;
+//   * per step and slab: a boundary launch (first and last local row) that also
+//     packs the halo rows, then the halo exchange on a second stream
+//     (RCCL send/recv over xGMI, or peer copies inside one process) which
+//     overlaps the interior launch on the compute stream; events join them;
+//   * no host synchronisation inside the step loop; per-step speed sums stay
+//     on the device (one double per step and slab) and are reduced once at
+//     the end of the run.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "../../include/lbm_mi355x.h"
+#include "lbm_kernels.hip.h"
+
+// ----------------------------------------------------------------- errors
+static thread_local char g_err[1024] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIPC(call)                                                                         \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(LBM_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" const char* lbm_last_error(void) { return g_err; }
+
+// ----------------------------------------------------------------- RCCL (loaded on demand)
+// Minimal declarations of the RCCL entry points used (rccl.h: ncclGetUniqueId,
+// ncclCommInitRank, ncclCommInitAll, ncclSend/ncclRecv, ncclGroupStart/End,
+// ncclAllReduce, ncclCommDestroy).  dlopen by SONAME so that inside a process
+// that already carries RCCL (PyTorch) the same instance is shared.
+namespace rccl {
+typedef struct ncclComm* comm_t;
+struct unique_id { char internal[128]; };
+enum { kFloat32 = 7, kFloat64 = 8, kSum = 0 };
+static int (*GetUniqueId)(unique_id*);
+static int (*CommInitRank)(comm_t*, int, unique_id, int);
+static int (*CommInitAll)(comm_t*, int, const int*);
+static int (*CommDestroy)(comm_t);
+static int (*Send)(const void*, size_t, int, int, comm_t, hipStream_t);
+static int (*Recv)(void*, size_t, int, int, comm_t, hipStream_t);
+static int (*GroupStart)();
+static int (*GroupEnd)();
+static int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t);
+static const char* (*GetErrorString)(int);
+static void* handle = nullptr;
+
+static int load() {
+  if (handle) return LBM_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {
+    handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (handle) break;
+  }
+  if (!handle) return fail(LBM_ERCCL, "cannot load librccl: %s", dlerror());
+#define SYM(var, name)                                                       \
+  *(void**)(&var) = dlsym(handle, name);                                     \
+  if (!var) return fail(LBM_ERCCL, "librccl lacks symbol %s", name);
+  SYM(GetUniqueId, "ncclGetUniqueId");
+  SYM(CommInitRank, "ncclCommInitRank");
+  SYM(CommInitAll, "ncclCommInitAll");
+  SYM(CommDestroy, "ncclCommDestroy");
+  SYM(Send, "ncclSend");
+  SYM(Recv, "ncclRecv");
+  SYM(GroupStart, "ncclGroupStart");
+  SYM(GroupEnd, "ncclGroupEnd");
+  SYM(AllReduce, "ncclAllReduce");
+  SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+  return LBM_OK;
+}
+}  // namespace rccl
+
+#define NCCLC(call)                                                                        \
+  do {                                                                                     \
+    int r_ = (call);                                                                       \
+    if (r_ != 0)                                                                           \
+      return fail(LBM_ERCCL, "%s failed: %s (%s:%d)", #call, rccl::GetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+
+// ----------------------------------------------------------------- context
+namespace {
+
+struct Slab {
+  int dev = 0;
+  int row0 = 0, nyl = 0;       // global rows [row0, row0+nyl)
+  int pitch = 0;               // floats per row
+  long plane = 0;              // floats per plane
+  float* lat[2] = {nullptr, nullptr};
+  uint8_t* blocked = nullptr;
+  float* ghost_s[2] = {nullptr, nullptr};  // halo received from the south neighbour: planes 2,5,6
+  float* ghost_n[2] = {nullptr, nullptr};  // halo received from the north neighbour: planes 4,7,8
+  float* send_s[2] = {nullptr, nullptr};   // own row 0, planes 4,7,8 (goes south)
+  float* send_n[2] = {nullptr, nullptr};   // own row nyl-1, planes 2,5,6 (goes north)
+  float* partials[2] = {nullptr, nullptr};
+  int partial_cap = 0;
+  double* sums = nullptr;      // one double per step of the current run
+  int sums_cap = 0;
+  double* scratch_d = nullptr; // small double scratch (derive / reductions)
+  int scratch_cap = 0;
+  hipStream_t sc = nullptr, sx = nullptr;
+  hipEvent_t ev_bnd[2] = {nullptr, nullptr}, ev_recv[2] = {nullptr, nullptr};
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+  int accel_row = -1;          // local index of global row ny-2, or -1
+  rccl::comm_t comm = nullptr;
+};
+
+}  // namespace
+
+struct lbm_ctx {
+  lbm_param p;
+  std::vector<Slab> slabs;     // slabs owned by THIS process
+  int exchange = LBM_EXCHANGE_AUTO;  // resolved: 0 = none
+  int cur = 0;                 // which lattice holds the current state
+  bool rank_mode = false;
+  int rank = 0, nranks = 1;    // position in the global ring (rank mode); else 0 / nslabs
+  long tot_fluid = 0;          // non-blocked cells of the GLOBAL lattice
+  int V = 1;                   // cells per thread
+  long variant = 0;
+  double gpu_ms = 0.0, wall_ms = 0.0;
+};
+
+namespace {
+
+int pick_vector_width(int nx) {
+  const char* e = getenv("LBM_VECTOR_WIDTH");
+  int want = e ? atoi(e) : 4;
+  if (want >= 4 && nx % 4 == 0 && nx >= 8) return 4;
+  if (want >= 2 && nx % 2 == 0 && nx >= 4) return 2;
+  return 1;
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+int slab_alloc(lbm_ctx* c, Slab& s, bool exchanging) {
+  HIPC(hipSetDevice(s.dev));
+  const int nx = c->p.nx;
+  s.pitch = (nx + 63) / 64 * 64;
+  s.plane = (long)s.nyl * s.pitch;
+  const size_t lat_bytes = sizeof(float) * 9 * (size_t)s.plane;
+  for (int i = 0; i < 2; ++i) HIPC(hipMalloc((void**)&s.lat[i], lat_bytes));
+  HIPC(hipMalloc((void**)&s.blocked, (size_t)s.plane));
+  // one partial per block; worst case V = 1, one launch covering all rows (+2 for split launches)
+  s.partial_cap = cdiv((long)s.nyl * nx, lbm::kBlock) + 4;
+  for (int i = 0; i < 2; ++i) HIPC(hipMalloc((void**)&s.partials[i], sizeof(float) * s.partial_cap));
+  s.scratch_cap = s.partial_cap;
+  HIPC(hipMalloc((void**)&s.scratch_d, sizeof(double) * (s.scratch_cap + 8)));
+  if (exchanging) {
+    const size_t hb = sizeof(float) * 3 * (size_t)nx;
+    for (int i = 0; i < 2; ++i) {
+      HIPC(hipMalloc((void**)&s.ghost_s[i], hb));
+      HIPC(hipMalloc((void**)&s.ghost_n[i], hb));
+      HIPC(hipMalloc((void**)&s.send_s[i], hb));
+      HIPC(hipMalloc((void**)&s.send_n[i], hb));
+    }
+  }
+  HIPC(hipStreamCreateWithFlags(&s.sc, hipStreamNonBlocking));
+  HIPC(hipStreamCreateWithFlags(&s.sx, hipStreamNonBlocking));
+  // everything that touches slab memory is ordered on s.sc (the streams are
+  // non-blocking: a null-stream memset would race with the first kernels)
+  HIPC(hipMemsetAsync(s.blocked, 0, (size_t)s.plane, s.sc));
+  for (int i = 0; i < 2; ++i) {
+    HIPC(hipEventCreateWithFlags(&s.ev_bnd[i], hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&s.ev_recv[i], hipEventDisableTiming));
+  }
+  HIPC(hipEventCreate(&s.ev_t0));
+  HIPC(hipEventCreate(&s.ev_t1));
+  return LBM_OK;
+}
+
+// Uploads the slab's rows of the global host arrays and converts to the device layout.
+int slab_upload(lbm_ctx* c, Slab& s, const int* obstacles, const float* cells) {
+  HIPC(hipSetDevice(s.dev));
+  const int nx = c->p.nx;
+  const long ncell = (long)s.nyl * nx;
+  const int grid = cdiv(ncell, 256);
+  {
+    int* d_ob = nullptr;
+    HIPC(hipMalloc((void**)&d_ob, sizeof(int) * ncell));
+    HIPC(hipMemcpyAsync(d_ob, obstacles + (long)s.row0 * nx, sizeof(int) * ncell, hipMemcpyHostToDevice, s.sc));
+    hipLaunchKernelGGL(lbm::lbm_pack_blocked, dim3(grid), dim3(256), 0, s.sc, d_ob, s.blocked, s.pitch, nx, ncell);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(s.sc));
+    HIPC(hipFree(d_ob));
+  }
+  if (cells != nullptr) {
+    float* d_aos = nullptr;
+    HIPC(hipMalloc((void**)&d_aos, sizeof(float) * 9 * ncell));
+    HIPC(hipMemcpyAsync(d_aos, cells + 9L * s.row0 * nx, sizeof(float) * 9 * ncell, hipMemcpyHostToDevice, s.sc));
+    hipLaunchKernelGGL(lbm::lbm_aos_to_soa, dim3(grid), dim3(256), 0, s.sc, d_aos, s.lat[c->cur], s.plane, s.pitch, nx, ncell);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(s.sc));
+    HIPC(hipFree(d_aos));
+  } else {
+    // rest equilibrium, every cell (d2q9-bgk.c:2802-2823); padding columns get it too
+    const float w0 = c->p.density * 4.f / 9.f, w1 = c->p.density / 9.f, w2 = c->p.density / 36.f;
+    hipLaunchKernelGGL(lbm::lbm_fill_equilibrium, dim3(cdiv(s.plane, 256)), dim3(256), 0, s.sc, s.lat[c->cur], s.plane, w0, w1, w2);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(s.sc));
+  }
+  // the other lattice is fully overwritten by the first step (padding columns never read)
+  return LBM_OK;
+}
+
+void slab_free(Slab& s) {
+  (void)hipSetDevice(s.dev);
+  for (int i = 0; i < 2; ++i) {
+    if (s.lat[i]) (void)hipFree(s.lat[i]);
+    if (s.partials[i]) (void)hipFree(s.partials[i]);
+    if (s.ghost_s[i]) (void)hipFree(s.ghost_s[i]);
+    if (s.ghost_n[i]) (void)hipFree(s.ghost_n[i]);
+    if (s.send_s[i]) (void)hipFree(s.send_s[i]);
+    if (s.send_n[i]) (void)hipFree(s.send_n[i]);
+    if (s.ev_bnd[i]) (void)hipEventDestroy(s.ev_bnd[i]);
+    if (s.ev_recv[i]) (void)hipEventDestroy(s.ev_recv[i]);
+  }
+  if (s.blocked) (void)hipFree(s.blocked);
+  if (s.sums) (void)hipFree(s.sums);
+  if (s.scratch_d) (void)hipFree(s.scratch_d);
+  if (s.ev_t0) (void)hipEventDestroy(s.ev_t0);
+  if (s.ev_t1) (void)hipEventDestroy(s.ev_t1);
+  if (s.comm) (void)rccl::CommDestroy(s.comm);
+  if (s.sc) (void)hipStreamDestroy(s.sc);
+  if (s.sx) (void)hipStreamDestroy(s.sx);
+}
+
+int check_params(const lbm_param* p) {
+  if (!p) return fail(LBM_EINVAL, "params is NULL");
+  if (p->nx < 1 || p->ny < 2) return fail(LBM_EINVAL, "lattice must be at least 1 x 2 (got %d x %d)", p->nx, p->ny);
+  if ((long)p->nx * p->ny > (1L << 31) - 1) return fail(LBM_EINVAL, "lattice too large for int cell indices");
+  return LBM_OK;
+}
+
+long count_fluid(const int* obstacles, long n) {
+  long f = 0;
+  for (long i = 0; i < n; ++i) f += obstacles[i] ? 0 : 1;
+  return f;
+}
+
+// Launches one sweep over rows y_begin + i*y_stride of slab s.
+template <int V>
+void launch_sweep_v(const lbm::SweepArgs& a, hipStream_t st) {
+  const long threads = (long)a.y_count * (a.nx / V);
+  const int grid = cdiv(threads, lbm::kBlock);
+  hipLaunchKernelGGL(lbm::lbm_sweep<V>, dim3(grid), dim3(lbm::kBlock), 0, st, a);
+}
+
+int sweep_blocks(const lbm_ctx* c, int y_count) {
+  return cdiv((long)y_count * (c->p.nx / c->V), lbm::kBlock);
+}
+
+void launch_sweep(const lbm_ctx* c, const lbm::SweepArgs& a, hipStream_t st) {
+  switch (c->V) {
+    case 4: launch_sweep_v<4>(a, st); break;
+    case 2: launch_sweep_v<2>(a, st); break;
+    default: launch_sweep_v<1>(a, st); break;
+  }
+}
+
+// Halo exchange for parity q on the exchange streams (all local slabs).
+int exchange_halos(lbm_ctx* c, int q) {
+  const size_t n = 3 * (size_t)c->p.nx;
+  const int ns = (int)c->slabs.size();
+  if (c->exchange == LBM_EXCHANGE_RCCL) {
+    for (auto& s : c->slabs) {
+      HIPC(hipSetDevice(s.dev));
+      HIPC(hipStreamWaitEvent(s.sx, s.ev_bnd[q], 0));
+    }
+    NCCLC(rccl::GroupStart());
+    for (int i = 0; i < ns; ++i) {
+      Slab& s = c->slabs[i];
+      const int me = c->rank_mode ? c->rank : i;
+      const int south = (me + c->nranks - 1) % c->nranks, north = (me + 1) % c->nranks;
+      // order matters when south == north (2 ranks): sends S then N, receives N then S
+      NCCLC(rccl::Send(s.send_s[q], n, rccl::kFloat32, south, s.comm, s.sx));
+      NCCLC(rccl::Send(s.send_n[q], n, rccl::kFloat32, north, s.comm, s.sx));
+      NCCLC(rccl::Recv(s.ghost_n[q], n, rccl::kFloat32, north, s.comm, s.sx));
+      NCCLC(rccl::Recv(s.ghost_s[q], n, rccl::kFloat32, south, s.comm, s.sx));
+    }
+    NCCLC(rccl::GroupEnd());
+    for (auto& s : c->slabs) {
+      HIPC(hipSetDevice(s.dev));
+      HIPC(hipEventRecord(s.ev_recv[q], s.sx));
+    }
+  } else {  // LBM_EXCHANGE_COPY: the receiver pulls from its neighbours' send buffers
+    for (int i = 0; i < ns; ++i) {
+      Slab& s = c->slabs[i];
+      Slab& so = c->slabs[(i + ns - 1) % ns];
+      Slab& no = c->slabs[(i + 1) % ns];
+      HIPC(hipSetDevice(s.dev));
+      HIPC(hipStreamWaitEvent(s.sx, s.ev_bnd[q], 0));
+      HIPC(hipStreamWaitEvent(s.sx, so.ev_bnd[q], 0));
+      HIPC(hipStreamWaitEvent(s.sx, no.ev_bnd[q], 0));
+      HIPC(hipMemcpyAsync(s.ghost_s[q], so.send_n[q], sizeof(float) * n, hipMemcpyDeviceToDevice, s.sx));
+      HIPC(hipMemcpyAsync(s.ghost_n[q], no.send_s[q], sizeof(float) * n, hipMemcpyDeviceToDevice, s.sx));
+      HIPC(hipEventRecord(s.ev_recv[q], s.sx));
+    }
+  }
+  return LBM_OK;
+}
+
+int ensure_sums(Slab& s, int nsteps) {
+  if (s.sums_cap >= nsteps) return LBM_OK;
+  HIPC(hipSetDevice(s.dev));
+  if (s.sums) HIPC(hipFree(s.sums));
+  s.sums = nullptr;
+  HIPC(hipMalloc((void**)&s.sums, sizeof(double) * nsteps));
+  s.sums_cap = nsteps;
+  return LBM_OK;
+}
+
+int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
+  const bool exchanging = c->exchange != 0;
+  const int ay = c->p.ny - 2;  // the accelerate row of the global lattice (d2q9-bgk.c:240)
+  for (auto& s : c->slabs) {
+    s.accel_row = (ay >= s.row0 && ay < s.row0 + s.nyl) ? ay - s.row0 : -1;
+    int rc = slab_alloc(c, s, exchanging);
+    if (rc) return rc;
+    rc = slab_upload(c, s, obstacles, cells);
+    if (rc) return rc;
+  }
+  return LBM_OK;
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------- C ABI
+extern "C" int lbm_device_count(int* count) {
+  if (!count) return fail(LBM_EINVAL, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+  *count = n;
+  return LBM_OK;
+}
+
+extern "C" int lbm_rccl_unique_id(void* id128) {
+  if (!id128) return fail(LBM_EINVAL, "id buffer is NULL");
+  int rc = rccl::load();
+  if (rc) return rc;
+  rccl::unique_id id;
+  NCCLC(rccl::GetUniqueId(&id));
+  memcpy(id128, &id, sizeof(id));
+  return LBM_OK;
+}
+
+extern "C" int lbm_create(const lbm_param* params, const int* obstacles, const float* cells,
+                          int nslabs, const int* devices, int exchange, lbm_ctx** out) {
+  if (!out) return fail(LBM_EINVAL, "out is NULL");
+  *out = nullptr;
+  int rc = check_params(params);
+  if (rc) return rc;
+  if (!obstacles) return fail(LBM_EINVAL, "obstacles is NULL");
+  if (nslabs < 1 || nslabs > params->ny) return fail(LBM_EINVAL, "nslabs must be in [1, ny] (got %d)", nslabs);
+  if (exchange < 0 || exchange > 2) return fail(LBM_EINVAL, "unknown exchange mode %d", exchange);
+  int ndev = 0;
+  lbm_device_count(&ndev);
+  if (ndev < 1) return fail(LBM_ENODEV, "no HIP device visible; this library has no CPU path");
+
+  lbm_ctx* c = new lbm_ctx();
+  c->p = *params;
+  c->nranks = nslabs;
+  c->V = pick_vector_width(params->nx);
+  const char* force = getenv("LBM_FORCE_EXCHANGE");
+  if (nslabs == 1 && !(force && atoi(force)))
+    c->exchange = 0;
+  else
+    c->exchange = (exchange == LBM_EXCHANGE_AUTO) ? LBM_EXCHANGE_RCCL : exchange;
+  c->tot_fluid = count_fluid(obstacles, (long)params->nx * params->ny);
+  c->slabs.resize(nslabs);
+  std::vector<int> devs(nslabs);
+  for (int i = 0; i < nslabs; ++i) {
+    Slab& s = c->slabs[i];
+    s.dev = devices ? devices[i] : i;
+    devs[i] = s.dev;
+    if (s.dev < 0 || s.dev >= ndev) {
+      delete c;
+      return fail(LBM_ENODEV, "slab %d wants HIP device %d but only %d visible", i, s.dev, ndev);
+    }
+    s.row0 = (int)((long)i * params->ny / nslabs);
+    s.nyl = (int)((long)(i + 1) * params->ny / nslabs) - s.row0;
+  }
+  rc = finish_create(c, obstacles, cells);
+  if (!rc && c->exchange == LBM_EXCHANGE_RCCL) {
+    rc = rccl::load();
+    if (!rc) {
+      std::vector<rccl::comm_t> comms(nslabs);
+      int r = rccl::CommInitAll(comms.data(), nslabs, devs.data());
+      if (r != 0) rc = fail(LBM_ERCCL, "ncclCommInitAll failed: %s", rccl::GetErrorString(r));
+      else for (int i = 0; i < nslabs; ++i) c->slabs[i].comm = comms[i];
+    }
+  }
+  if (rc) { std::string keep = g_err; lbm_destroy(c); snprintf(g_err, sizeof(g_err), "%s", keep.c_str()); return rc; }
+  *out = c;
+  return LBM_OK;
+}
+
+extern "C" int lbm_create_rank(const lbm_param* params, const int* obstacles, const float* cells,
+                               int rank, int nranks, int device, const void* unique_id, lbm_ctx** out) {
+  if (!out) return fail(LBM_EINVAL, "out is NULL");
+  *out = nullptr;
+  int rc = check_params(params);
+  if (rc) return rc;
+  if (!obstacles) return fail(LBM_EINVAL, "obstacles is NULL");
+  if (nranks < 1 || nranks > params->ny || rank < 0 || rank >= nranks)
+    return fail(LBM_EINVAL, "bad rank %d of %d (ny = %d)", rank, nranks, params->ny);
+  int ndev = 0;
+  lbm_device_count(&ndev);
+  if (ndev < 1) return fail(LBM_ENODEV, "no HIP device visible; this library has no CPU path");
+  if (device < 0 || device >= ndev) return fail(LBM_ENODEV, "HIP device %d not visible (%d devices)", device, ndev);
+  const char* force = getenv("LBM_FORCE_EXCHANGE");
+  const bool exchanging = nranks > 1 || (force && atoi(force));
+  if (exchanging && !unique_id) return fail(LBM_EINVAL, "unique_id is NULL");
+
+  lbm_ctx* c = new lbm_ctx();
+  c->p = *params;
+  c->rank_mode = true;
+  c->rank = rank;
+  c->nranks = nranks;
+  c->V = pick_vector_width(params->nx);
+  c->exchange = exchanging ? LBM_EXCHANGE_RCCL : 0;
+  c->tot_fluid = count_fluid(obstacles, (long)params->nx * params->ny);
+  c->slabs.resize(1);
+  Slab& s = c->slabs[0];
+  s.dev = device;
+  s.row0 = (int)((long)rank * params->ny / nranks);
+  s.nyl = (int)((long)(rank + 1) * params->ny / nranks) - s.row0;
+  rc = finish_create(c, obstacles, cells);
+  if (!rc && (exchanging || nranks > 1)) {
+    rc = rccl::load();
+    if (!rc) {
+      rccl::unique_id id;
+      memcpy(&id, unique_id, sizeof(id));
+      if (hipSetDevice(device) != hipSuccess) rc = fail(LBM_EHIP, "hipSetDevice(%d) failed", device);
+      if (!rc) {
+        int r = rccl::CommInitRank(&s.comm, nranks, id, rank);
+        if (r != 0) rc = fail(LBM_ERCCL, "ncclCommInitRank failed: %s", rccl::GetErrorString(r));
+      }
+    }
+  }
+  if (rc) { std::string keep = g_err; lbm_destroy(c); snprintf(g_err, sizeof(g_err), "%s", keep.c_str()); return rc; }
+  *out = c;
+  return LBM_OK;
+}
+
+extern "C" int lbm_num_slabs(const lbm_ctx* ctx) { return ctx ? (int)ctx->slabs.size() : 0; }
+
+extern "C" int lbm_slab_rows(const lbm_ctx* ctx, int slab, int* row_begin, int* row_end) {
+  if (!ctx || slab < 0 || slab >= (int)ctx->slabs.size()) return fail(LBM_EINVAL, "bad slab index");
+  if (row_begin) *row_begin = ctx->slabs[slab].row0;
+  if (row_end) *row_end = ctx->slabs[slab].row0 + ctx->slabs[slab].nyl;
+  return LBM_OK;
+}
+
+extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
+  if (!c) return fail(LBM_EINVAL, "ctx is NULL");
+  if (nsteps < 0) return fail(LBM_EINVAL, "nsteps < 0");
+  if (nsteps == 0) { c->gpu_ms = c->wall_ms = 0.0; return LBM_OK; }
+  const int nx = c->p.nx;
+  const float a1 = c->p.density * c->p.accel / 9.f;   // d2q9-bgk.c:230-231
+  const float a2 = c->p.density * c->p.accel / 36.f;
+  const bool ex = c->exchange != 0;
+  int rc;
+
+  for (auto& s : c->slabs)
+    if ((rc = ensure_sums(s, nsteps))) return rc;
+
+  // ---- prologue: accelerate phase of the first step; first halo exchange
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    if (s.accel_row >= 0) {
+      hipLaunchKernelGGL(lbm::lbm_accelerate_row, dim3(cdiv(nx, 256)), dim3(256), 0, s.sc,
+                         s.lat[c->cur], s.plane, s.pitch, nx, s.accel_row, s.blocked, a1, a2);
+      HIPC(hipGetLastError());
+    }
+    if (ex) {
+      hipLaunchKernelGGL(lbm::lbm_pack_halos, dim3(cdiv(nx, 256)), dim3(256), 0, s.sc,
+                         s.lat[c->cur], s.plane, s.pitch, nx, s.nyl, s.send_s[1], s.send_n[1]);
+      HIPC(hipGetLastError());
+      HIPC(hipEventRecord(s.ev_bnd[1], s.sc));
+    }
+  }
+  if (ex && (rc = exchange_halos(c, 1))) return rc;
+
+  const auto wall0 = std::chrono::steady_clock::now();
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    HIPC(hipEventRecord(s.ev_t0, s.sc));
+  }
+
+  // ---- the step loop (reference d2q9-bgk.c:180-201); no host sync inside
+  for (int tt = 0; tt < nsteps; ++tt) {
+    const int q = tt & 1, qp = q ^ 1;
+    const bool last = (tt == nsteps - 1);
+    for (auto& s : c->slabs) {
+      HIPC(hipSetDevice(s.dev));
+      lbm::SweepArgs a;
+      a.src = s.lat[c->cur];
+      a.dst = s.lat[c->cur ^ 1];
+      a.plane = s.plane; a.pitch = s.pitch; a.nx = nx; a.nyl = s.nyl;
+      a.blocked = s.blocked;
+      a.omega = c->p.omega;
+      a.accel_row = last ? -1 : s.accel_row;
+      a.a1 = a1; a.a2 = a2;
+      a.partials = s.partials[q];
+      a.prev_partials = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
+      if (!ex) {
+        // one slab, periodic self-wrap: the halo rows are the slab's own edge rows
+        const long top = (long)(s.nyl - 1) * s.pitch;
+        a.south2 = a.src + 2 * s.plane + top; a.south5 = a.src + 5 * s.plane + top; a.south6 = a.src + 6 * s.plane + top;
+        a.north4 = a.src + 4 * s.plane; a.north7 = a.src + 7 * s.plane; a.north8 = a.src + 8 * s.plane;
+        a.send_south = a.send_north = nullptr;
+        a.y_begin = 0; a.y_count = s.nyl; a.y_stride = 1;
+        const int nb = sweep_blocks(c, a.y_count);
+        if (tt > 0) { a.prev_partials = s.partials[qp]; a.prev_count = nb; a.prev_sum = s.sums + (tt - 1); }
+        launch_sweep(c, a, s.sc);
+        HIPC(hipGetLastError());
+      } else {
+        a.south2 = s.ghost_s[qp]; a.south5 = s.ghost_s[qp] + nx; a.south6 = s.ghost_s[qp] + 2 * nx;
+        a.north4 = s.ghost_n[qp]; a.north7 = s.ghost_n[qp] + nx; a.north8 = s.ghost_n[qp] + 2 * nx;
+        a.send_south = s.send_s[q]; a.send_north = s.send_n[q];
+        // boundary rows first: they feed the exchange
+        const int nb_rows = s.nyl >= 2 ? 2 : 1;
+        a.y_begin = 0; a.y_count = nb_rows; a.y_stride = s.nyl >= 2 ? s.nyl - 1 : 1;
+        const int nbb = sweep_blocks(c, nb_rows);
+        const int nbi = s.nyl > 2 ? sweep_blocks(c, s.nyl - 2) : 0;
+        if (tt > 0) { a.prev_partials = s.partials[qp]; a.prev_count = nbb + nbi; a.prev_sum = s.sums + (tt - 1); }
+        HIPC(hipStreamWaitEvent(s.sc, s.ev_recv[qp], 0));
+        launch_sweep(c, a, s.sc);
+        HIPC(hipGetLastError());
+        HIPC(hipEventRecord(s.ev_bnd[q], s.sc));
+      }
+    }
+    if (ex) {
+      if ((rc = exchange_halos(c, q))) return rc;
+      for (auto& s : c->slabs) {
+        if (s.nyl <= 2) continue;
+        HIPC(hipSetDevice(s.dev));
+        lbm::SweepArgs a;
+        a.src = s.lat[c->cur];
+        a.dst = s.lat[c->cur ^ 1];
+        a.plane = s.plane; a.pitch = s.pitch; a.nx = nx; a.nyl = s.nyl;
+        a.blocked = s.blocked;
+        a.omega = c->p.omega;
+        a.accel_row = last ? -1 : s.accel_row;
+        a.a1 = a1; a.a2 = a2;
+        a.south2 = a.south5 = a.south6 = a.north4 = a.north7 = a.north8 = nullptr;  // interior rows never touch halos
+        a.send_south = a.send_north = nullptr;
+        a.y_begin = 1; a.y_count = s.nyl - 2; a.y_stride = 1;
+        a.partials = s.partials[q] + sweep_blocks(c, 2);
+        a.prev_partials = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
+        launch_sweep(c, a, s.sc);
+        HIPC(hipGetLastError());
+      }
+    }
+    c->cur ^= 1;
+  }
+
+  // ---- epilogue: fold the last step's partials, collect the per-step sums
+  const int ql = (nsteps - 1) & 1;
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    int count;
+    if (!ex) count = sweep_blocks(c, s.nyl);
+    else count = sweep_blocks(c, s.nyl >= 2 ? 2 : 1) + (s.nyl > 2 ? sweep_blocks(c, s.nyl - 2) : 0);
+    hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql], count, s.sums + (nsteps - 1));
+    HIPC(hipGetLastError());
+    HIPC(hipEventRecord(s.ev_t1, s.sc));
+    if (ex) HIPC(hipStreamWaitEvent(s.sc, s.ev_recv[ql], 0));  // drain the last exchange
+  }
+  if (c->rank_mode && c->nranks > 1) {
+    Slab& s = c->slabs[0];
+    NCCLC(rccl::AllReduce(s.sums, s.sums, (size_t)nsteps, rccl::kFloat64, rccl::kSum, s.comm, s.sc));
+  }
+  std::vector<double> acc(nsteps, 0.0), tmp(nsteps);
+  double gpu_ms = 0.0;
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    HIPC(hipStreamSynchronize(s.sx));
+    HIPC(hipStreamSynchronize(s.sc));
+    float ms = 0.f;
+    HIPC(hipEventElapsedTime(&ms, s.ev_t0, s.ev_t1));
+    if (ms > gpu_ms) gpu_ms = ms;
+    if (av_vels) {
+      HIPC(hipMemcpy(tmp.data(), s.sums, sizeof(double) * nsteps, hipMemcpyDeviceToHost));
+      for (int i = 0; i < nsteps; ++i) acc[i] += tmp[i];
+    }
+  }
+  c->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  c->gpu_ms = gpu_ms;
+  if (av_vels)
+    for (int i = 0; i < nsteps; ++i) av_vels[i] = (float)(acc[i] / (double)c->tot_fluid);  // d2q9-bgk.c:1811
+  return LBM_OK;
+}
+
+extern "C" int lbm_last_run_ms(const lbm_ctx* c, double* gpu_ms, double* wall_ms) {
+  if (!c) return fail(LBM_EINVAL, "ctx is NULL");
+  if (gpu_ms) *gpu_ms = c->gpu_ms;
+  if (wall_ms) *wall_ms = c->wall_ms;
+  return LBM_OK;
+}
+
+extern "C" int lbm_read_state(lbm_ctx* c, float* out) {
+  if (!c || !out) return fail(LBM_EINVAL, "NULL argument");
+  const int nx = c->p.nx;
+  const int base_row = c->rank_mode ? c->slabs[0].row0 : 0;
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    const long ncell = (long)s.nyl * nx;
+    float* d_aos = nullptr;
+    HIPC(hipMalloc((void**)&d_aos, sizeof(float) * 9 * ncell));
+    hipLaunchKernelGGL(lbm::lbm_soa_to_aos, dim3(cdiv(ncell, 256)), dim3(256), 0, s.sc, s.lat[c->cur], d_aos, s.plane, s.pitch, nx, ncell);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(s.sc));
+    HIPC(hipMemcpy(out + 9L * (s.row0 - base_row) * nx, d_aos, sizeof(float) * 9 * ncell, hipMemcpyDeviceToHost));
+    HIPC(hipFree(d_aos));
+  }
+  return LBM_OK;
+}
+
+// Runs lbm_derive on every local slab; returns global speed sum and mass.
+static int derive_all(lbm_ctx* c, float* out4, double* speed_sum, double* mass) {
+  const int nx = c->p.nx;
+  const int base_row = c->rank_mode ? c->slabs[0].row0 : 0;
+  double tot[2] = {0.0, 0.0};
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    const long ncell = (long)s.nyl * nx;
+    const int grid = cdiv(ncell, lbm::kBlock);
+    float* d_out = nullptr;
+    if (out4) HIPC(hipMalloc((void**)&d_out, sizeof(float) * 4 * ncell));
+    float* part = s.partials[0];  // idle between runs; capacity >= grid
+    double* mpart = s.scratch_d;
+    double* res = s.scratch_d + s.scratch_cap;  // 2 doubles: speed, mass
+    hipLaunchKernelGGL(lbm::lbm_derive, dim3(grid), dim3(lbm::kBlock), 0, s.sc, s.lat[c->cur], s.plane, s.pitch, nx, ncell,
+                       s.blocked, c->p.density, d_out, part, mpart);
+    HIPC(hipGetLastError());
+    hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, part, grid, res);
+    hipLaunchKernelGGL(lbm::lbm_fold_double, dim3(1), dim3(lbm::kBlock), 0, s.sc, mpart, grid, res + 1);
+    HIPC(hipGetLastError());
+    if (c->rank_mode && c->nranks > 1)
+      NCCLC(rccl::AllReduce(res, res, 2, rccl::kFloat64, rccl::kSum, s.comm, s.sc));
+    HIPC(hipStreamSynchronize(s.sc));
+    double h[2];
+    HIPC(hipMemcpy(h, res, sizeof(h), hipMemcpyDeviceToHost));
+    tot[0] += h[0]; tot[1] += h[1];
+    if (out4) {
+      HIPC(hipMemcpy(out4 + 4L * (s.row0 - base_row) * nx, d_out, sizeof(float) * 4 * ncell, hipMemcpyDeviceToHost));
+      HIPC(hipFree(d_out));
+    }
+  }
+  if (speed_sum) *speed_sum = tot[0];
+  if (mass) *mass = tot[1];
+  return LBM_OK;
+}
+
+extern "C" int lbm_av_velocity(lbm_ctx* c, float* out) {
+  if (!c || !out) return fail(LBM_EINVAL, "NULL argument");
+  double sp = 0.0;
+  int rc = derive_all(c, nullptr, &sp, nullptr);
+  if (rc) return rc;
+  *out = (float)(sp / (double)c->tot_fluid);  // d2q9-bgk.c:2713
+  return LBM_OK;
+}
+
+extern "C" int lbm_reynolds(lbm_ctx* c, float* out) {
+  if (!c || !out) return fail(LBM_EINVAL, "NULL argument");
+  float av = 0.f;
+  int rc = lbm_av_velocity(c, &av);
+  if (rc) return rc;
+  const float viscosity = 1.f / 6.f * (2.f / c->p.omega - 1.f);  // d2q9-bgk.c:2895
+  *out = av * c->p.reynolds_dim / viscosity;
+  return LBM_OK;
+}
+
+extern "C" int lbm_total_density(lbm_ctx* c, double* out) {
+  if (!c || !out) return fail(LBM_EINVAL, "NULL argument");
+  return derive_all(c, nullptr, nullptr, out);
+}
+
+extern "C" int lbm_final_state(lbm_ctx* c, float* out) {
+  if (!c || !out) return fail(LBM_EINVAL, "NULL argument");
+  return derive_all(c, out, nullptr, nullptr);
+}
+
+extern "C" int lbm_destroy(lbm_ctx* c) {
+  if (!c) return LBM_OK;
+  for (auto& s : c->slabs) slab_free(s);
+  delete c;
+  return LBM_OK;
+}
+
+extern "C" int lbm_timestep(const lbm_param* params, float* cells, float* tmp_cells,
+                            const int* obstacles, float* av_vel) {
+  if (!cells || !tmp_cells) return fail(LBM_EINVAL, "NULL lattice");
+  lbm_ctx* c = nullptr;
+  int rc = lbm_create(params, obstacles, cells, 1, nullptr, LBM_EXCHANGE_AUTO, &c);
+  if (rc) return rc;
+  float av = 0.f;
+  rc = lbm_run(c, 1, &av);
+  if (!rc) rc = lbm_read_state(c, tmp_cells);
+  lbm_destroy(c);
+  if (rc) return rc;
+  // the reference mutates `cells` (accelerate, row ny-2, d2q9-bgk.c:230-260): do the same
+  // host-side so that callers relying on that side effect see it
+  {
+    const float a1 = params->density * params->accel / 9.f, a2 = params->density * params->accel / 36.f;
+    const int jj = params->ny - 2;
+    for (int ii = 0; ii < params->nx; ++ii) {
+      float* s = cells + 9L * (ii + (long)jj * params->nx);
+      if (!obstacles[ii + jj * params->nx] && (s[3] - a1) > 0.f && (s[6] - a2) > 0.f && (s[7] - a2) > 0.f) {
+        s[1] += a1; s[5] += a2; s[8] += a2; s[3] -= a1; s[6] -= a2; s[7] -= a2;
+      }
+    }
+  }
+  if (av_vel) *av_vel = av;
+  return LBM_OK;
+}
+
+extern "C" int lbm_set_option(lbm_ctx* c, const char* key, long value) {
+  if (!c || !key) return fail(LBM_EINVAL, "NULL argument");
+  if (!strcmp(key, "vector_width")) {
+    if (!(value == 1 || (value == 2 && c->p.nx % 2 == 0 && c->p.nx >= 4) || (value == 4 && c->p.nx % 4 == 0 && c->p.nx >= 8)))
+      return fail(LBM_EINVAL, "vector_width %ld not usable with nx = %d", value, c->p.nx);
+    c->V = (int)value;
+    return LBM_OK;
+  }
+  if (!strcmp(key, "kernel_variant")) { c->variant = value; return LBM_OK; }
+  return fail(LBM_EINVAL, "unknown option %s", key);
+}
+
+extern "C" int lbm_get_info(const lbm_ctx* c, const char* key, double* value) {
+  if (!c || !key || !value) return fail(LBM_EINVAL, "NULL argument");
+  if (!strcmp(key, "vector_width")) { *value = c->V; return LBM_OK; }
+  if (!strcmp(key, "fluid_cells")) { *value = (double)c->tot_fluid; return LBM_OK; }
+  if (!strcmp(key, "exchange")) { *value = c->exchange; return LBM_OK; }
+  if (!strcmp(key, "pitch")) { *value = c->slabs[0].pitch; return LBM_OK; }
+  if (!strcmp(key, "hbm_bytes")) {
+    double b = 0;
+    for (auto& s : c->slabs) b += 2.0 * 9 * 4 * (double)s.plane + (double)s.plane;
+    *value = b; return LBM_OK;
+  }
+  return fail(LBM_EINVAL, "unknown info key %s", key);
+}

@@ -1,0 +1,424 @@
+// lbm_kernels.hip.h -- hand-written HIP kernels for the D2Q9-BGK time step on
+// CDNA4 (gfx950, wave64).  Device code only; the C ABI lives in lbm_api.hip.
+//
+// What one launch of lbm_sweep does for every cell of the rows it covers
+// (the reference's fused step, /root/reference/d2q9-bgk.c:228-1813, in one
+// pull-scheme pass over SoA planes):
+//   pull-stream  (gather map d2q9-bgk.c:2139-2147)
+//   bounce-back  on blocked cells (d2q9-bgk.c:971-981)
+//   BGK collide  on fluid cells   (d2q9-bgk.c:982-1100)
+//   |u'| of the stored values, summed per block for av_vels (d2q9-bgk.c:1103-1130)
+//   accelerate   (d2q9-bgk.c:230-260) -- applied AT WRITE TIME to row ny-2 of
+//                the lattice being written, i.e. the accelerate phase of the
+//                NEXT step, in the same float operations (SURVEY.md §7 hard
+//                part 1b); a one-row prologue kernel covers the first step and
+//                the last step of a run leaves the lattice unbiased.
+//
+// Data layout in HBM (per slab of nyl rows): 9 planes of nyl x pitch floats,
+// plane k = distribution k, x fastest; one byte per cell for the blocked map.
+// A thread owns V consecutive cells of one row, so the unshifted planes move as
+// one 16-byte access per lane (V = 4) and a wave covers 1 KiB per plane and row.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lbm {
+
+constexpr int kBlock = 256;  // 4 waves of 64
+
+struct SweepArgs {
+  const float* src;            // source lattice: plane k at src + k*plane
+  float* dst;                  // destination lattice
+  long plane;                  // floats per plane (nyl * pitch)
+  int pitch;                   // floats per row
+  int nx;                      // cells per row
+  int nyl;                     // rows in this slab
+  // rows covered by this launch: y = y_begin + i*y_stride, i in [0, y_count)
+  int y_begin, y_count, y_stride;
+  // "row -1": planes 2,5,6 of the slab to the south (or own top row if alone)
+  const float* south2; const float* south5; const float* south6;
+  // "row nyl": planes 4,7,8 of the slab to the north (or own row 0 if alone)
+  const float* north4; const float* north7; const float* north8;
+  const uint8_t* blocked;      // nyl * pitch bytes, 1 = obstacle
+  float omega;
+  int accel_row;               // local row that receives the next step's accelerate, or -1
+  float a1, a2;                // density*accel/9, density*accel/36
+  float* partials;             // one float per block of this launch: sum of |u'|
+  float* send_south;           // 3*nx floats (planes 4,7,8 of row 0) or nullptr
+  float* send_north;           // 3*nx floats (planes 2,5,6 of row nyl-1) or nullptr
+  // fold-in of the previous step's block partials (block 0 only)
+  const float* prev_partials;  // or nullptr
+  int prev_count;
+  double* prev_sum;            // where the previous step's slab sum goes
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Block-wide sum; result valid in thread 0.  `red` holds one slot per wave.
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  T r = T(0);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) r += red[w];
+  }
+  return r;
+}
+
+// One cell: p[] holds the nine pulled values on entry and the nine values to
+// store on exit.  Returns the cell's contribution to the step's speed sum.
+// Arithmetic follows SURVEY.md Appendix A (= d2q9-bgk.c:982-1130) with
+// c_sq = 1/3 folded into the constants: 1/c_sq = 3, 1/(2 c_sq^2) = 4.5,
+// 1/(2 c_sq) = 1.5, and one reciprocal of the density shared by both
+// velocity components (the reference's own -Ofast build does the same).
+__device__ __forceinline__ float collide_cell(float (&p)[9], bool is_blocked, float omega) {
+  const float w0 = 4.f / 9.f, w1 = 1.f / 9.f, w2 = 1.f / 36.f;
+  float rho = p[0];
+  rho += p[1]; rho += p[2]; rho += p[3]; rho += p[4];
+  rho += p[5]; rho += p[6]; rho += p[7]; rho += p[8];
+  const float inv = 1.0f / rho;
+  const float ux = (p[1] + p[5] + p[8] - (p[3] + p[6] + p[7])) * inv;
+  const float uy = (p[2] + p[5] + p[6] - (p[4] + p[7] + p[8])) * inv;
+  const float usq = ux * ux + uy * uy;
+  const float base = 1.f - 1.5f * usq;
+  const float r1 = w1 * rho, r2 = w2 * rho;
+  const float upp = ux + uy, upm = ux - uy;
+  float d[9];
+  d[0] = w0 * rho * base;
+  d[1] = r1 * (base + ux * (3.f + 4.5f * ux));
+  d[2] = r1 * (base + uy * (3.f + 4.5f * uy));
+  d[3] = r1 * (base - ux * (3.f - 4.5f * ux));
+  d[4] = r1 * (base - uy * (3.f - 4.5f * uy));
+  d[5] = r2 * (base + upp * (3.f + 4.5f * upp));
+  d[6] = r2 * (base - upm * (3.f - 4.5f * upm));
+  d[7] = r2 * (base - upp * (3.f - 4.5f * upp));
+  d[8] = r2 * (base + upm * (3.f + 4.5f * upm));
+  float t[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) t[k] = p[k] + omega * (d[k] - p[k]);
+  // post-collision speed from the values about to be stored
+  float rho2 = t[0];
+#pragma unroll
+  for (int k = 1; k < 9; ++k) rho2 += t[k];
+  const float inv2 = 1.0f / rho2;
+  const float vx = (t[1] + t[5] + t[8] - (t[3] + t[6] + t[7])) * inv2;
+  const float vy = (t[2] + t[5] + t[6] - (t[4] + t[7] + t[8])) * inv2;
+  const float speed = sqrtf(vx * vx + vy * vy);
+  // blocked cell: mirrored pulled values instead, no contribution
+  const float b1 = p[3], b2 = p[4], b3 = p[1], b4 = p[2], b5 = p[7], b6 = p[8], b7 = p[5], b8 = p[6];
+  p[0] = is_blocked ? p[0] : t[0];
+  p[1] = is_blocked ? b1 : t[1];
+  p[2] = is_blocked ? b2 : t[2];
+  p[3] = is_blocked ? b3 : t[3];
+  p[4] = is_blocked ? b4 : t[4];
+  p[5] = is_blocked ? b5 : t[5];
+  p[6] = is_blocked ? b6 : t[6];
+  p[7] = is_blocked ? b7 : t[7];
+  p[8] = is_blocked ? b8 : t[8];
+  return is_blocked ? 0.f : speed;
+}
+
+// The accelerate phase for one cell of row ny-2 (d2q9-bgk.c:246-258).
+__device__ __forceinline__ void accelerate_cell(float (&p)[9], bool is_blocked, float a1, float a2) {
+  if (!is_blocked && (p[3] - a1) > 0.f && (p[6] - a2) > 0.f && (p[7] - a2) > 0.f) {
+    p[1] += a1; p[5] += a2; p[8] += a2;
+    p[3] -= a1; p[6] -= a2; p[7] -= a2;
+  }
+}
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-B access, 4-B aligned
+typedef float f4a __attribute__((ext_vector_type(4), aligned(16)));
+typedef float f2a __attribute__((ext_vector_type(2), aligned(8)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+// V consecutive values of a row, shifted by one cell to the west / east, with
+// the periodic wrap of the reference (x_w = ii ? ii-1 : nx-1, x_e = (ii+1)%nx;
+// d2q9-bgk.c:2133-2135).
+template <int V> struct Row;
+
+template <> struct Row<1> {
+  static __device__ __forceinline__ void ld(const float* r, int x0, float (&o)[1]) { o[0] = r[x0]; }
+  static __device__ __forceinline__ void ld_w(const float* r, int x0, int nx, float (&o)[1]) {
+    o[0] = r[x0 ? x0 - 1 : nx - 1];
+  }
+  static __device__ __forceinline__ void ld_e(const float* r, int x0, int nx, float (&o)[1]) {
+    o[0] = r[x0 + 1 == nx ? 0 : x0 + 1];
+  }
+  static __device__ __forceinline__ void st(float* r, int x0, const float (&v)[1]) { r[x0] = v[0]; }
+};
+
+template <> struct Row<2> {
+  static __device__ __forceinline__ void ld(const float* r, int x0, float (&o)[2]) {
+    const f2a v = *reinterpret_cast<const f2a*>(r + x0);
+    o[0] = v.x; o[1] = v.y;
+  }
+  static __device__ __forceinline__ void ld_w(const float* r, int x0, int nx, float (&o)[2]) {
+    if (x0 > 0) {
+      const f2u v = *reinterpret_cast<const f2u*>(r + x0 - 1);
+      o[0] = v.x; o[1] = v.y;
+    } else {
+      o[0] = r[nx - 1]; o[1] = r[0];
+    }
+  }
+  static __device__ __forceinline__ void ld_e(const float* r, int x0, int nx, float (&o)[2]) {
+    if (x0 + 2 < nx) {
+      const f2u v = *reinterpret_cast<const f2u*>(r + x0 + 1);
+      o[0] = v.x; o[1] = v.y;
+    } else {
+      o[0] = r[x0 + 1]; o[1] = r[0];
+    }
+  }
+  static __device__ __forceinline__ void st(float* r, int x0, const float (&v)[2]) {
+    f2a o; o.x = v[0]; o.y = v[1];
+    *reinterpret_cast<f2a*>(r + x0) = o;
+  }
+};
+
+template <> struct Row<4> {
+  static __device__ __forceinline__ void ld(const float* r, int x0, float (&o)[4]) {
+    const f4a v = *reinterpret_cast<const f4a*>(r + x0);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+  static __device__ __forceinline__ void ld_w(const float* r, int x0, int nx, float (&o)[4]) {
+    if (x0 > 0) {
+      const f4u v = *reinterpret_cast<const f4u*>(r + x0 - 1);
+      o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else {
+      o[0] = r[nx - 1]; o[1] = r[0]; o[2] = r[1]; o[3] = r[2];
+    }
+  }
+  static __device__ __forceinline__ void ld_e(const float* r, int x0, int nx, float (&o)[4]) {
+    if (x0 + 4 < nx) {
+      const f4u v = *reinterpret_cast<const f4u*>(r + x0 + 1);
+      o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else {
+      o[0] = r[x0 + 1]; o[1] = r[x0 + 2]; o[2] = r[x0 + 3]; o[3] = r[0];
+    }
+  }
+  static __device__ __forceinline__ void st(float* r, int x0, const float (&v)[4]) {
+    f4a o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+    *reinterpret_cast<f4a*>(r + x0) = o;
+  }
+};
+
+// The fused step.  Requires nx % V == 0 (host picks V); any nyl >= 1.
+template <int V>
+__global__ __launch_bounds__(kBlock) void lbm_sweep(const SweepArgs a) {
+  __shared__ float red_f[kBlock / 64];
+  __shared__ double red_d[kBlock / 64];
+
+  // Block 0 first folds the previous step's per-block partials into one
+  // double per step: deterministic (fixed order), no atomics, no extra launch.
+  if (blockIdx.x == 0 && a.prev_partials != nullptr) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < a.prev_count; i += kBlock) s += (double)a.prev_partials[i];
+    s = block_sum<double>(s, red_d);
+    if (threadIdx.x == 0) *a.prev_sum = s;
+  }
+
+  const int nxv = a.nx / V;
+  const long gid = (long)blockIdx.x * kBlock + threadIdx.x;
+  const int ri = (int)(gid / nxv);
+  const int x0 = (int)(gid - (long)ri * nxv) * V;
+  float local = 0.f;
+
+  if (ri < a.y_count) {
+    const int y = a.y_begin + ri * a.y_stride;
+    const long rc = (long)y * a.pitch;
+    const float* s = a.src;
+    const long P = a.plane;
+    // centre row
+    const float* r0 = s + rc;
+    const float* r1 = s + P + rc;
+    const float* r3 = s + 3 * P + rc;
+    // row to the south (y-1) and to the north (y+1), halo rows at the slab edges
+    const bool at_s = (y == 0), at_n = (y == a.nyl - 1);
+    const float* r2 = at_s ? a.south2 : s + 2 * P + rc - a.pitch;
+    const float* r5 = at_s ? a.south5 : s + 5 * P + rc - a.pitch;
+    const float* r6 = at_s ? a.south6 : s + 6 * P + rc - a.pitch;
+    const float* r4 = at_n ? a.north4 : s + 4 * P + rc + a.pitch;
+    const float* r7 = at_n ? a.north7 : s + 7 * P + rc + a.pitch;
+    const float* r8 = at_n ? a.north8 : s + 8 * P + rc + a.pitch;
+
+    float q[9][V];
+    Row<V>::ld(r0, x0, q[0]);
+    Row<V>::ld_w(r1, x0, a.nx, q[1]);
+    Row<V>::ld(r2, x0, q[2]);
+    Row<V>::ld_e(r3, x0, a.nx, q[3]);
+    Row<V>::ld(r4, x0, q[4]);
+    Row<V>::ld_w(r5, x0, a.nx, q[5]);
+    Row<V>::ld_e(r6, x0, a.nx, q[6]);
+    Row<V>::ld_e(r7, x0, a.nx, q[7]);
+    Row<V>::ld_w(r8, x0, a.nx, q[8]);
+
+    bool blk[V];
+    if constexpr (V == 4) {
+      const uint32_t m = *reinterpret_cast<const uint32_t*>(a.blocked + rc + x0);
+      blk[0] = m & 0xffu; blk[1] = m & 0xff00u; blk[2] = m & 0xff0000u; blk[3] = m & 0xff000000u;
+    } else if constexpr (V == 2) {
+      const uint16_t m = *reinterpret_cast<const uint16_t*>(a.blocked + rc + x0);
+      blk[0] = m & 0xffu; blk[1] = m & 0xff00u;
+    } else {
+      blk[0] = a.blocked[rc + x0] != 0;
+    }
+
+    const bool do_accel = (y == a.accel_row);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      float p[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) p[k] = q[k][v];
+      local += collide_cell(p, blk[v], a.omega);
+      if (do_accel) accelerate_cell(p, blk[v], a.a1, a.a2);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) q[k][v] = p[k];
+    }
+
+    float* d = a.dst + rc;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Row<V>::st(d + k * P, x0, q[k]);
+
+    // packed halo rows for the neighbouring slabs (multi-slab runs only)
+    if (at_s && a.send_south != nullptr) {
+      Row<V>::st(a.send_south, x0, q[4]);
+      Row<V>::st(a.send_south + a.nx, x0, q[7]);
+      Row<V>::st(a.send_south + 2 * a.nx, x0, q[8]);
+    }
+    if (at_n && a.send_north != nullptr) {
+      Row<V>::st(a.send_north, x0, q[2]);
+      Row<V>::st(a.send_north + a.nx, x0, q[5]);
+      Row<V>::st(a.send_north + 2 * a.nx, x0, q[6]);
+    }
+  }
+
+  const float bs = block_sum<float>(local, red_f);
+  if (threadIdx.x == 0) a.partials[blockIdx.x] = bs;
+}
+
+// Folds a step's block partials into its slab sum (after the last step of a run).
+__global__ __launch_bounds__(kBlock) void lbm_fold_partials(const float* partials, int count, double* out) {
+  __shared__ double red_d[kBlock / 64];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < count; i += kBlock) s += (double)partials[i];
+  s = block_sum<double>(s, red_d);
+  if (threadIdx.x == 0) *out = s;
+}
+
+// Accelerate phase on one row of a resident lattice (first step of a run).
+__global__ void lbm_accelerate_row(float* lat, long plane, int pitch, int nx, int row,
+                                   const uint8_t* blocked, float a1, float a2) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= nx) return;
+  const long c = (long)row * pitch + x;
+  if (blocked[c]) return;
+  const float f3 = lat[3 * plane + c], f6 = lat[6 * plane + c], f7 = lat[7 * plane + c];
+  if ((f3 - a1) > 0.f && (f6 - a2) > 0.f && (f7 - a2) > 0.f) {
+    lat[1 * plane + c] += a1; lat[5 * plane + c] += a2; lat[8 * plane + c] += a2;
+    lat[3 * plane + c] = f3 - a1; lat[6 * plane + c] = f6 - a2; lat[7 * plane + c] = f7 - a2;
+  }
+}
+
+// Packs the halo rows of a resident lattice (start of a run: nothing has been
+// sent yet).  out_s = planes 4,7,8 of row 0; out_n = planes 2,5,6 of row nyl-1.
+__global__ void lbm_pack_halos(const float* lat, long plane, int pitch, int nx, int nyl,
+                               float* out_s, float* out_n) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= nx) return;
+  const long top = (long)(nyl - 1) * pitch + x;
+  out_s[x] = lat[4 * plane + x]; out_s[nx + x] = lat[7 * plane + x]; out_s[2 * nx + x] = lat[8 * plane + x];
+  out_n[x] = lat[2 * plane + top]; out_n[nx + x] = lat[5 * plane + top]; out_n[2 * nx + x] = lat[6 * plane + top];
+}
+
+// Host layout <-> device layout.  aos = t_speed[rows*nx] (9 floats per cell).
+__global__ void lbm_aos_to_soa(const float* aos, float* lat, long plane, int pitch, int nx, long ncell) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  const long y = c / nx; const int x = (int)(c - y * nx);
+  const long o = y * pitch + x;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) lat[k * plane + o] = aos[9 * c + k];
+}
+__global__ void lbm_soa_to_aos(const float* lat, float* aos, long plane, int pitch, int nx, long ncell) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  const long y = c / nx; const int x = (int)(c - y * nx);
+  const long o = y * pitch + x;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) aos[9 * c + k] = lat[k * plane + o];
+}
+__global__ void lbm_fill_equilibrium(float* lat, long plane, float w0, float w1, float w2) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= plane) return;
+  lat[i] = w0;
+#pragma unroll
+  for (int k = 1; k < 5; ++k) lat[k * plane + i] = w1;
+#pragma unroll
+  for (int k = 5; k < 9; ++k) lat[k * plane + i] = w2;
+}
+__global__ void lbm_pack_blocked(const int* obst, uint8_t* blocked, int pitch, int nx, long ncell) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  const long y = c / nx; const int x = (int)(c - y * nx);
+  blocked[y * pitch + x] = obst[c] ? 1 : 0;
+}
+
+// Derived fields of write_values() (d2q9-bgk.c:2935-2976) and the speed sum of
+// av_velocity() (d2q9-bgk.c:2665-2714) in one pass.  out4 may be nullptr.
+__global__ __launch_bounds__(kBlock) void lbm_derive(const float* lat, long plane, int pitch, int nx,
+                                                     long ncell, const uint8_t* blocked, float density,
+                                                     float* out4, float* partials, double* mass_partials) {
+  __shared__ float red_f[kBlock / 64];
+  __shared__ double red_d[kBlock / 64];
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float sp = 0.f;
+  double mass = 0.0;
+  if (c < ncell) {
+    const long y = c / nx; const int x = (int)(c - y * nx);
+    const long o = y * pitch + x;
+    float f[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) f[k] = lat[k * plane + o];
+    float rho = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rho += f[k];
+    mass = (double)rho;
+    float ux = 0.f, uy = 0.f, u = 0.f, pr = density * (1.f / 3.f);
+    if (!blocked[o]) {
+      ux = (f[1] + f[5] + f[8] - (f[3] + f[6] + f[7])) / rho;
+      uy = (f[2] + f[5] + f[6] - (f[4] + f[7] + f[8])) / rho;
+      u = sqrtf(ux * ux + uy * uy);
+      pr = rho * (1.f / 3.f);
+      sp = u;
+    }
+    if (out4 != nullptr) {
+      f4a v; v.x = ux; v.y = uy; v.z = u; v.w = pr;
+      *reinterpret_cast<f4a*>(out4 + 4 * c) = v;
+    }
+  }
+  const float bs = block_sum<float>(sp, red_f);
+  const double bm = block_sum<double>(mass, red_d);
+  if (threadIdx.x == 0) { partials[blockIdx.x] = bs; mass_partials[blockIdx.x] = bm; }
+}
+
+__global__ __launch_bounds__(kBlock) void lbm_fold_double(const double* in, int count, double* out) {
+  __shared__ double red_d[kBlock / 64];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < count; i += kBlock) s += in[i];
+  s = block_sum<double>(s, red_d);
+  if (threadIdx.x == 0) *out = s;
+}
+
+}  // namespace lbm

@@ -1,0 +1,195 @@
+/*
+** d2q9-bgk (MI355X): thin C host around the HIP time-step library.
+**
+** Keeps the external contract of the reference program
+** (/root/reference/d2q9-bgk.c): the command line
+**
+**   ./d2q9-bgk <paramfile> <obstaclefile>
+**
+** (main, d2q9-bgk.c:146-226), the two input text formats (initialise,
+** d2q9-bgk.c:2716-2869), the two output files written into the current
+** directory (write_values, d2q9-bgk.c:2918-2999), the stdout block
+** (d2q9-bgk.c:216-221) and the error convention (die/usage,
+** d2q9-bgk.c:3001-3013).  Everything between reading the inputs and writing
+** the outputs happens on the GPU through include/lbm_mi355x.h; this file holds
+** no lattice arithmetic.
+**
+** Optional environment (the two-argument form stays unchanged):
+**   LBM_NGPUS=n        row-partition the lattice over n GPUs (default 1)
+**   LBM_EXCHANGE=rccl|copy   halo transport between slabs (default rccl)
+**   LBM_SKIP_FINAL_STATE=1   do not write final_state.dat (huge synthetic lattices)
+*/
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+
+#include "lbm_mi355x.h"
+
+#define FINALSTATEFILE "final_state.dat"
+#define AVVELSFILE     "av_vels.dat"
+
+static void die(const char* message, const int line, const char* file)
+{
+  fprintf(stderr, "Error at line %d of file %s:\n", line, file);
+  fprintf(stderr, "%s\n", message);
+  fflush(stderr);
+  exit(EXIT_FAILURE);
+}
+
+static void usage(const char* exe)
+{
+  fprintf(stderr, "Usage: %s <paramfile> <obstaclefile>\n", exe);
+  exit(EXIT_FAILURE);
+}
+
+static double wtime(void)
+{
+  struct timeval t;
+  gettimeofday(&t, NULL);
+  return t.tv_sec + t.tv_usec / 1000000.0;
+}
+
+/* library failure -> the reference's die() convention */
+#define LBM_CALL(call) \
+  do { if ((call) != LBM_OK) die(lbm_last_error(), __LINE__, __FILE__); } while (0)
+
+/* paramfile: seven values, one per line (d2q9-bgk.c:2736-2762) */
+static void read_params(const char* paramfile, lbm_param* p)
+{
+  char message[1024];
+  FILE* fp = fopen(paramfile, "r");
+  if (fp == NULL) {
+    snprintf(message, sizeof(message), "could not open input parameter file: %s", paramfile);
+    die(message, __LINE__, __FILE__);
+  }
+  if (fscanf(fp, "%d\n", &p->nx) != 1) die("could not read param file: nx", __LINE__, __FILE__);
+  if (fscanf(fp, "%d\n", &p->ny) != 1) die("could not read param file: ny", __LINE__, __FILE__);
+  if (fscanf(fp, "%d\n", &p->maxIters) != 1) die("could not read param file: maxIters", __LINE__, __FILE__);
+  if (fscanf(fp, "%d\n", &p->reynolds_dim) != 1) die("could not read param file: reynolds_dim", __LINE__, __FILE__);
+  if (fscanf(fp, "%f\n", &p->density) != 1) die("could not read param file: density", __LINE__, __FILE__);
+  if (fscanf(fp, "%f\n", &p->accel) != 1) die("could not read param file: accel", __LINE__, __FILE__);
+  if (fscanf(fp, "%f\n", &p->omega) != 1) die("could not read param file: omega", __LINE__, __FILE__);
+  fclose(fp);
+}
+
+/* obstaclefile: lines "x y 1" until EOF (d2q9-bgk.c:2826-2860) */
+static int* read_obstacles(const char* obstaclefile, const lbm_param* p)
+{
+  char message[1024];
+  int xx, yy, blocked, retval;
+  int* obstacles = calloc((size_t)p->nx * p->ny, sizeof(int));
+  if (obstacles == NULL) die("cannot allocate column memory for obstacles", __LINE__, __FILE__);
+  FILE* fp = fopen(obstaclefile, "r");
+  if (fp == NULL) {
+    snprintf(message, sizeof(message), "could not open input obstacles file: %s", obstaclefile);
+    die(message, __LINE__, __FILE__);
+  }
+  while ((retval = fscanf(fp, "%d %d %d\n", &xx, &yy, &blocked)) != EOF) {
+    if (retval != 3) die("expected 3 values per line in obstacle file", __LINE__, __FILE__);
+    if (xx < 0 || xx > p->nx - 1) die("obstacle x-coord out of range", __LINE__, __FILE__);
+    if (yy < 0 || yy > p->ny - 1) die("obstacle y-coord out of range", __LINE__, __FILE__);
+    if (blocked != 1) die("obstacle blocked value should be 1", __LINE__, __FILE__);
+    obstacles[xx + (size_t)yy * p->nx] = blocked;
+  }
+  fclose(fp);
+  return obstacles;
+}
+
+/* final_state.dat and av_vels.dat, line formats of d2q9-bgk.c:2978 and 2993.
+** The flag column prints obstacles[ii + jj*nx], which is what the shipped golden
+** files contain (the reference prints the transposed element). */
+static void write_values(const lbm_param* p, const float* state4, const int* obstacles,
+                         const float* av_vels, int write_final_state)
+{
+  FILE* fp;
+  if (write_final_state) {
+    fp = fopen(FINALSTATEFILE, "w");
+    if (fp == NULL) die("could not open file output file", __LINE__, __FILE__);
+    static char iobuf[1 << 22];
+    setvbuf(fp, iobuf, _IOFBF, sizeof(iobuf));
+    for (int jj = 0; jj < p->ny; jj++) {
+      for (int ii = 0; ii < p->nx; ii++) {
+        const size_t c = ii + (size_t)jj * p->nx;
+        const float* v = state4 + 4 * c;
+        fprintf(fp, "%d %d %.12E %.12E %.12E %.12E %d\n", ii, jj, v[0], v[1], v[2], v[3], obstacles[c]);
+      }
+    }
+    fclose(fp);
+  }
+  fp = fopen(AVVELSFILE, "w");
+  if (fp == NULL) die("could not open file output file", __LINE__, __FILE__);
+  for (int ii = 0; ii < p->maxIters; ii++) fprintf(fp, "%d:\t%.12E\n", ii, av_vels[ii]);
+  fclose(fp);
+}
+
+int main(int argc, char* argv[])
+{
+  char* paramfile = NULL;
+  char* obstaclefile = NULL;
+  lbm_param params;
+  double tot_tic, tot_toc, init_tic, init_toc, comp_tic, comp_toc, col_tic, col_toc;
+
+  if (argc != 3) usage(argv[0]);
+  paramfile = argv[1];
+  obstaclefile = argv[2];
+
+  const char* e;
+  int ngpus = (e = getenv("LBM_NGPUS")) ? atoi(e) : 1;
+  int exchange = LBM_EXCHANGE_AUTO;
+  if ((e = getenv("LBM_EXCHANGE")) && !strcmp(e, "copy")) exchange = LBM_EXCHANGE_COPY;
+  const int skip_final = (e = getenv("LBM_SKIP_FINAL_STATE")) && atoi(e);
+  if (ngpus < 1) die("LBM_NGPUS must be >= 1", __LINE__, __FILE__);
+
+  /* Total/init time starts here */
+  tot_tic = init_tic = wtime();
+  read_params(paramfile, &params);
+  int* obstacles = read_obstacles(obstaclefile, &params);
+  float* av_vels = malloc(sizeof(float) * (params.maxIters > 0 ? params.maxIters : 1));
+  if (av_vels == NULL) die("cannot allocate memory for av_vels", __LINE__, __FILE__);
+  lbm_ctx* ctx = NULL;
+  /* NULL cells: the library starts from the rest equilibrium (d2q9-bgk.c:2802-2823) */
+  LBM_CALL(lbm_create(&params, obstacles, NULL, ngpus, NULL, exchange, &ctx));
+
+  /* Init time stops here, compute time starts */
+  init_toc = comp_tic = wtime();
+  LBM_CALL(lbm_run(ctx, params.maxIters, av_vels));   /* the loop of d2q9-bgk.c:180-201 */
+  comp_toc = col_tic = wtime();
+
+  /* Collate: slabs -> host (derived fields are computed on the GPU) */
+  float reynolds = 0.f;
+  LBM_CALL(lbm_reynolds(ctx, &reynolds));
+  float* state4 = NULL;
+  if (!skip_final) {
+    state4 = malloc(sizeof(float) * 4 * (size_t)params.nx * params.ny);
+    if (state4 == NULL) die("cannot allocate memory for final state", __LINE__, __FILE__);
+    LBM_CALL(lbm_final_state(ctx, state4));
+  }
+  col_toc = tot_toc = wtime();
+
+  printf("==done==\n");
+  printf("Reynolds number:\t\t%.12E\n", reynolds);
+  printf("Elapsed Init time:\t\t\t%.6lf (s)\n", init_toc - init_tic);
+  printf("Elapsed Compute time:\t\t\t%.6lf (s)\n", comp_toc - comp_tic);
+  printf("Elapsed Collate time:\t\t\t%.6lf (s)\n", col_toc - col_tic);
+  printf("Elapsed Total time:\t\t\t%.6lf (s)\n", tot_toc - tot_tic);
+  /* extra lines, after the reference's block */
+  {
+    double gpu_ms = 0.0, wall_ms = 0.0;
+    lbm_last_run_ms(ctx, &gpu_ms, &wall_ms);
+    const double lups = (double)params.nx * params.ny * params.maxIters;
+    const double mlups = gpu_ms > 0 ? lups / (gpu_ms * 1e-3) / 1e6 : 0.0;
+    printf("GPUs:\t\t\t\t\t%d\n", ngpus);
+    printf("Step-loop GPU time:\t\t\t%.6lf (s)\n", gpu_ms * 1e-3);
+    printf("MLUPS:\t\t\t\t\t%.1f\n", mlups);
+    printf("Algorithmic HBM GB/s (72 B/LUP):\t%.1f\n", mlups * 72.0 / 1000.0);
+    printf("Fraction of HBM roofline (8 TB/s x GPUs):\t%.4f\n", mlups * 72.0 / 1000.0 / (8000.0 * ngpus));
+  }
+  write_values(&params, state4, obstacles, av_vels, !skip_final);
+
+  LBM_CALL(lbm_destroy(ctx));
+  free(state4);
+  free(av_vels);
+  free(obstacles);
+  return EXIT_SUCCESS;
+}
