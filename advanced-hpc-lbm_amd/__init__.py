@@ -328,6 +328,13 @@ def write_values(params: Param, state4: np.ndarray, obstacles: np.ndarray, av_ve
 
 
 # ------------------------------------------------------------------ row slabs
+# What crosses a slab boundary each step (the pull stencil, d2q9-bgk.c:971-998): a slab's
+# bottom row is pulled into by the slab to the south through directions 4,7,8, its top row by
+# the slab to the north through 2,5,6 -- three planes of one row per direction, 3*nx floats.
+HALO_PLANES_TO_SOUTH = (4, 7, 8)   # of the sender's row 0
+HALO_PLANES_TO_NORTH = (2, 5, 6)   # of the sender's last row
+
+
 def slab_bounds(ny: int, nslabs: int, slab: int):
     """Rows [begin, end) of slab `slab`: the library's own partition rule."""
     return slab * ny // nslabs, (slab + 1) * ny // nslabs

@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MLUPS of the D2Q9-BGK time-step path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 1024x1024|8192x8192]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one lattice sweep (the reference's timestep_new2 + swap, d2q9-bgk.c:182,190)
+of the whole lattice.  The default workload is the configuration BASELINE.json quotes its
+metric on -- the shipped 1024x1024 deck -- row-partitioned over the N GPUs (strong scaling);
+the synthetic 8192x8192 lattice of BASELINE.json is measured in the same run and reported
+under "also".  Inputs are resident in HBM before the timed region; exactly K steps are
+timed between barrier + torch.cuda.synchronize() pairs; the maximum over ranks is used.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the sweep kernel against HBM:
+72 algorithmic bytes per lattice update (9 float reads + 9 float writes, mask excluded)
+x the cells one launch covers / the mean launch time measured with HIP events on the
+library's own compute stream.  `cpu_baseline` times the serial reference on this host
+(oracle/_ref/d2q9-bgk, built from the reference's own source; else our port) on a bounded
+sample of the same deck.
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (before the HIP library: both link libamdhip64.so.7)
+import torch.distributed as dist  # noqa: E402
+
+import advanced_hpc_lbm_amd as L  # noqa: E402
+
+BYTES_PER_LUP = 72.0     # 9 float32 reads + 9 float32 writes
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def synthetic_obstacles(n: int) -> np.ndarray:
+    """BASELINE.json's synthetic deck: the 1024x1024 geometry scaled by n/1024 -- closed box
+    plus a full-height wall at x = n/3 (2730 for 8192)."""
+    ob = np.zeros((n, n), dtype=np.int32)
+    ob[0, :] = ob[-1, :] = 1
+    ob[:, 0] = ob[:, -1] = 1
+    ob[:, (341 * n) // 1024] = 1
+    return ob
+
+
+def make_workload(name: str):
+    if name == "1024x1024":
+        p = L.read_params(os.path.join(ROOT, "input_1024x1024.params"))
+        ob = L.read_obstacles(os.path.join(ROOT, "obstacles_1024x1024.dat"), p)
+        data = "shipped deck input_1024x1024.params + obstacles_1024x1024.dat, rest-equilibrium start"
+    else:
+        m = re.fullmatch(r"(\d+)x(\d+)", name)
+        if not m or m.group(1) != m.group(2):
+            raise SystemExit(f"unknown workload {name}")
+        n = int(m.group(1))
+        p = L.Param(n, n, 1000, 10, 0.1, 0.01, 1.85)
+        ob = synthetic_obstacles(n)
+        data = f"synthetic {n}x{n}: box walls + full-height wall at x={(341 * n) // 1024}, rest-equilibrium start"
+    return p, ob, data
+
+
+def measure(name, world, rank, local_rank, uid, steps, warmup):
+    """Creates the resident lattice, warms up, times exactly `steps` steps."""
+    p, ob, data = make_workload(name)
+    if world > 1:
+        lat = L.Lattice(p, ob, rank=rank, nranks=world, device=local_rank, unique_id=uid)
+    else:
+        lat = L.Lattice(p, ob, nslabs=1, devices=[local_rank])
+    r0, r1 = lat.slab_rows(0)
+    if warmup > 0:
+        lat.run(warmup)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    av = lat.run(steps)
+    fence()
+    dt = time.perf_counter() - t0
+    gpu_ms, _ = lat.last_run_ms()
+    if world > 1:
+        t = torch.tensor([dt, gpu_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, gpu_ms = t[0].item(), t[1].item()
+    vw = int(lat.info("vector_width"))
+    lat.close()
+    cells = p.nx * p.ny
+    local_cells = p.nx * (r1 - r0)
+    launch_s = gpu_ms * 1e-3 / steps                     # mean duration of one step's launch(es) on this GPU
+    achieved = BYTES_PER_LUP * local_cells / launch_s / 1e9
+    return {
+        "mlups": cells * steps / dt / 1e6,
+        "ms_per_step": dt * 1e3 / steps,
+        "gpu_ms_per_step": gpu_ms / steps,
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": lookup_traffic(name, world),
+                     "kernel": f"lbm_sweep<{vw}>", "bytes_per_launch": BYTES_PER_LUP * local_cells},
+        "data": data, "params": p, "blocked": int(ob.sum()), "av_last": float(av[-1]), "finite": bool(np.isfinite(av).all()),
+    }
+
+
+def lookup_traffic(name, world):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path)).get(name, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(sample_steps: int):
+    """Serial CPU reference on this host, 1 core, on the 1024x1024 deck cut to `sample_steps` steps
+    (rate metric; the reference's own 'Elapsed Compute time' interval, d2q9-bgk.c:176-178,204-206)."""
+    ncores = os.cpu_count()
+    model = ""
+    try:
+        model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+    except Exception:
+        pass
+    exe = os.path.join(ROOT, "oracle", "_ref", "d2q9-bgk")
+    lups = 1024 * 1024 * sample_steps
+    if os.path.exists(exe):
+        with tempfile.TemporaryDirectory() as td:
+            pf = os.path.join(td, "sample.params")
+            with open(pf, "w") as f:
+                f.write(f"1024\n1024\n{sample_steps}\n10\n0.1\n0.01\n1.85\n")
+            r = subprocess.run([exe, pf, os.path.join(ROOT, "obstacles_1024x1024.dat")], cwd=td,
+                               capture_output=True, text=True)
+        m = re.search(r"Elapsed Compute time:\s+([0-9.]+)", r.stdout)
+        if r.returncode == 0 and m and float(m.group(1)) > 0:
+            secs = float(m.group(1))
+            return {"value": round(lups / secs / 1e6, 2), "unit": "MLUPS", "cores": 1, "kind": "reference",
+                    "sample": f"reference d2q9-bgk.c (its Makefile flags, -march=x86-64-v3) on the 1024x1024 deck, "
+                              f"{sample_steps} of 20000 steps, {secs:.2f} s compute",
+                    "host": f"{model}, {ncores} logical cores visible"}
+    # no reference binary here: time our own port of it (oracle/, reference flags)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import lbm_oracle as O
+    orc = O.Oracle("fast")
+    prm = O.read_params(os.path.join(ROOT, "input_1024x1024.params"))
+    ob = O.read_obstacles(os.path.join(ROOT, "obstacles_1024x1024.dat"), prm.nx, prm.ny)
+    cells = orc.init_cells(prm, np.float32)
+    t0 = time.perf_counter()
+    orc.run(prm, cells, ob, sample_steps)
+    secs = time.perf_counter() - t0
+    return {"value": round(lups / secs / 1e6, 2), "unit": "MLUPS", "cores": 1, "kind": "port",
+            "sample": f"oracle float port (-Ofast) on the 1024x1024 deck, {sample_steps} of 20000 steps, {secs:.2f} s",
+            "host": f"{model}, {ncores} logical cores visible"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20000, help="timed steps of the headline workload")
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="1024x1024")
+    ap.add_argument("--also", default="8192x8192", help="second workload reported under 'also' ('' to skip)")
+    ap.add_argument("--also-steps", type=int, default=300)
+    ap.add_argument("--cpu-sample-steps", type=int, default=600, help="0 = skip the CPU baseline")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available() or L.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    uid = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        buf = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            buf.copy_(torch.frombuffer(bytearray(L.rccl_unique_id()), dtype=torch.uint8))
+        dist.broadcast(buf, src=0)
+        uid = bytes(buf.cpu().numpy().tobytes())
+
+    head = measure(args.workload, world, rank, local_rank, uid, args.steps, args.warmup)
+    also = None
+    if args.also and args.also != args.workload:
+        if world > 1:  # a second communicator for the second lattice
+            buf = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                buf.copy_(torch.frombuffer(bytearray(L.rccl_unique_id()), dtype=torch.uint8))
+            dist.broadcast(buf, src=0)
+            uid = bytes(buf.cpu().numpy().tobytes())
+        also = measure(args.also, world, rank, local_rank, uid, args.also_steps, min(args.warmup, 20))
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_sample_steps > 0:
+        cpu = cpu_baseline(args.cpu_sample_steps)
+
+    if rank == 0:
+        p = head["params"]
+        line = {
+            "metric": "MLUPS (million lattice updates/sec), D2Q9-BGK time-step loop",
+            "value": round(head["mlups"], 1),
+            "unit": "MLUPS",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(head["ms_per_step"], 6),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": head["data"],
+            "config": {"workload": f"d2q9-bgk {args.workload}, {head['blocked']} blocked cells, "
+                                   f"density {p.density:g} accel {p.accel:g} omega {p.omega:g}",
+                       "nx": p.nx, "ny": p.ny, "decomposition": f"{world} row slab(s), one per GPU",
+                       "halo": "none (periodic self-wrap)" if world == 1 else "RCCL send/recv, 3*nx floats per direction per step"},
+            "roofline": head["roofline"],
+            "cpu_baseline": cpu,
+            "hbm_frac_of_peak_whole_job": round(head["mlups"] * BYTES_PER_LUP / 1e3 / (HBM_PEAK_GBS * world), 4),
+            "results_finite": head["finite"],
+        }
+        if also is not None:
+            line["also"] = {args.also: {
+                "value": round(also["mlups"], 1), "unit": "MLUPS", "steps": args.also_steps,
+                "ms_per_step": round(also["ms_per_step"], 6), "roofline": also["roofline"], "data": also["data"],
+                "hbm_frac_of_peak_whole_job": round(also["mlups"] * BYTES_PER_LUP / 1e3 / (HBM_PEAK_GBS * world), 4)}}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,7 +77,8 @@ class Oracle:
             for fn in ("orc_sweep_", "orc_timestep_", "orc_av_velocity_", "orc_reynolds_",
                        "orc_total_density_"):
                 getattr(self.lib, fn + suf).restype = ct
-            for fn in ("orc_init_cells_", "orc_accelerate_", "orc_run_", "orc_final_state_"):
+            for fn in ("orc_init_cells_", "orc_accelerate_", "orc_run_", "orc_final_state_",
+                       "orc_sweep_rows_", "orc_accelerate_row_"):
                 getattr(self.lib, fn + suf).restype = None
 
     @staticmethod
@@ -100,6 +101,19 @@ class Oracle:
     def sweep(self, prm, cells, tmp, obstacles) -> float:
         return getattr(self.lib, "orc_sweep_" + self._suf(cells.dtype))(
             C.byref(prm), self._p(cells), self._p(tmp), self._p(obstacles))
+
+    def sweep_rows(self, prm, cells, tmp, obstacles, row_begin: int, row_end: int):
+        """Sweep rows [row_begin, row_end) only -> (speed_sum, fluid_cells)."""
+        ct = _F[np.dtype(cells.dtype).type][1]
+        tot, cnt = ct(0), C.c_int(0)
+        getattr(self.lib, "orc_sweep_rows_" + self._suf(cells.dtype))(
+            C.byref(prm), self._p(cells), self._p(tmp), self._p(obstacles),
+            C.c_int(row_begin), C.c_int(row_end), C.byref(tot), C.byref(cnt))
+        return tot.value, cnt.value
+
+    def accelerate_row(self, prm, cells, obstacles, row: int):
+        getattr(self.lib, "orc_accelerate_row_" + self._suf(cells.dtype))(
+            C.byref(prm), self._p(cells), self._p(obstacles), C.c_int(row))
 
     def timestep(self, prm, cells, tmp, obstacles) -> float:
         return getattr(self.lib, "orc_timestep_" + self._suf(cells.dtype))(

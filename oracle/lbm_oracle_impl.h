@@ -173,6 +173,60 @@ ORC_REAL ORC_FN(orc_sweep_)(const orc_param* p, const ORC_REAL* cells, ORC_REAL*
   return tot_u / (ORC_REAL)tot_cells;
 }
 
+/* Row-range form of the sweep, for slab-decomposition tests: processes rows
+ * [row_begin, row_end) of a lattice of p->ny rows (periodic indexing over those
+ * p->ny rows, exactly as above), leaves other rows of tmp_cells untouched and
+ * returns the UN-normalised speed sum and the fluid-cell count of the range.
+ * A slab with one halo row on each side is a lattice of nyl+2 rows swept over
+ * [1, nyl+1).  Same cell arithmetic as orc_sweep_ (d2q9-bgk.c:971-1131). */
+void ORC_FN(orc_sweep_rows_)(const orc_param* p, const ORC_REAL* cells, ORC_REAL* tmp_cells,
+                             const int* obstacles, int row_begin, int row_end,
+                             ORC_REAL* tot_u_out, int* tot_cells_out)
+{
+  const int nx = p->nx, ny = p->ny;
+  int tot_cells = 0;
+  ORC_REAL tot_u = (ORC_REAL)0;
+  for (int jj = row_begin; jj < row_end; jj++) {
+    const int y_n = (jj + 1) % ny;
+    const int y_s = (jj == 0) ? (ny - 1) : (jj - 1);
+    for (int ii = 0; ii < nx; ii++) {
+      const int x_e = (ii + 1) % nx;
+      const int x_w = (ii == 0) ? (nx - 1) : (ii - 1);
+      ORC_REAL speed;
+      const long c0 = (long)ii + (long)jj * nx;
+      if (ORC_FN(orc_cell_)(p, cells, tmp_cells + 9 * c0, obstacles[c0], c0,
+                            (long)x_e + (long)jj * nx, (long)ii + (long)y_n * nx,
+                            (long)x_w + (long)jj * nx, (long)ii + (long)y_s * nx,
+                            (long)x_e + (long)y_n * nx, (long)x_w + (long)y_n * nx,
+                            (long)x_w + (long)y_s * nx, (long)x_e + (long)y_s * nx,
+                            &speed)) {
+        tot_u += speed;
+        ++tot_cells;
+      }
+    }
+  }
+  *tot_u_out = tot_u;
+  *tot_cells_out = tot_cells;
+}
+
+/* Accelerate phase on an arbitrary row (slab tests: the global row ny-2 has a
+ * different local index).  Same arithmetic as orc_accelerate_. */
+void ORC_FN(orc_accelerate_row_)(const orc_param* p, ORC_REAL* cells, const int* obstacles, int jj)
+{
+  const ORC_REAL a1 = (ORC_REAL)p->density * (ORC_REAL)p->accel / (ORC_REAL)9;
+  const ORC_REAL a2 = (ORC_REAL)p->density * (ORC_REAL)p->accel / (ORC_REAL)36;
+  for (int ii = 0; ii < p->nx; ii++) {
+    ORC_REAL* s = cells + 9 * ((long)ii + (long)jj * p->nx);
+    if (!obstacles[ii + jj * p->nx]
+        && (s[3] - a1) > (ORC_REAL)0
+        && (s[6] - a2) > (ORC_REAL)0
+        && (s[7] - a2) > (ORC_REAL)0) {
+      s[1] += a1; s[5] += a2; s[8] += a2;
+      s[3] -= a1; s[6] -= a2; s[7] -= a2;
+    }
+  }
+}
+
 /* One full reference time step (accelerate + sweep).  The caller swaps the
  * lattices afterwards, as main does at d2q9-bgk.c:182,190.
  * Reference signature: timestep_new2, d2q9-bgk.c:98,228. */

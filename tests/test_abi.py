@@ -1,0 +1,67 @@
+"""The C-ABI shared library loads and exports every symbol include/lbm_mi355x.h declares
+(no compute without a GPU), and fails loudly -- never falls back -- when no device exists."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "lbm_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lbm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(L):
+    assert _declared_symbols() == sorted(L.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(L):
+    lib = C.CDLL(L.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_param_struct_matches_reference_t_param(L):
+    """t_param = 4 ints + 3 floats, 28 bytes (d2q9-bgk.c:64-73)."""
+    assert C.sizeof(L.Param) == 28
+    assert [f[0] for f in L.Param._fields_] == ["nx", "ny", "maxIters", "reynolds_dim", "density", "accel", "omega"]
+
+
+def test_no_device_is_an_error_not_a_fallback(L):
+    if L.device_count() > 0:
+        pytest.skip("a HIP device is visible here")
+    p = L.Param(8, 8, 1, 1, 0.1, 0.005, 1.85)
+    with pytest.raises(L.LbmError, match="no HIP device"):
+        L.Lattice(p, np.zeros((8, 8), np.int32))
+    cells = np.zeros((8, 8, 9), np.float32)
+    with pytest.raises(L.LbmError, match="no HIP device"):
+        L.timestep_new2(p, cells, cells.copy(), np.zeros((8, 8), np.int32))
+
+
+def test_bad_arguments_are_rejected(L):
+    lib = L.load_library()
+    ctx = C.c_void_p()
+    p = L.Param(8, 1, 1, 1, 0.1, 0.005, 1.85)   # ny = 1: accelerate row ny-2 does not exist
+    ob = np.zeros(8, np.int32)
+    assert lib.lbm_create(C.byref(p), ob.ctypes.data, None, 1, None, 0, C.byref(ctx)) == 1
+    assert b"at least" in lib.lbm_last_error()
+    p = L.Param(8, 8, 1, 1, 0.1, 0.005, 1.85)
+    assert lib.lbm_create(C.byref(p), None, None, 1, None, 0, C.byref(ctx)) == 1
+    assert lib.lbm_create(C.byref(p), ob.ctypes.data, None, 0, None, 0, C.byref(ctx)) == 1
+    assert lib.lbm_run(None, 1, None) == 1
+
+
+def test_product_never_touches_the_oracle():
+    """Nothing under advanced-hpc-lbm_amd/ or the CLI host may reference oracle/."""
+    pkg = os.path.join(ROOT, "advanced-hpc-lbm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "lbm_oracle" not in text and "liblbm_oracle" not in text, f
+                assert not re.search(r"^\s*(import|from)\s+oracle", text, flags=re.M), f
