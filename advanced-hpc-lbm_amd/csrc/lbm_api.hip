@@ -157,7 +157,10 @@ int slab_alloc(lbm_ctx* c, Slab& s, bool exchanging) {
   HIPC(hipSetDevice(s.dev));
   const int nx = c->p.nx;
   s.pitch = (nx + 63) / 64 * 64;
-  s.plane = (long)s.nyl * s.pitch;
+  // Plane stride: rows + 4 KiB.  A power-of-two stride (8192^2: exactly 256 MiB) puts the
+  // same cell of all nine planes on the same HBM channel; 4 KiB of padding spreads the 18
+  // concurrent streams (kbench: plain 9-plane copy 4.9 -> 5.4 TB/s, sweep 5.35 -> 5.6 TB/s).
+  s.plane = (long)s.nyl * s.pitch + 1024;
   const size_t lat_bytes = sizeof(float) * 9 * (size_t)s.plane;
   for (int i = 0; i < 2; ++i) HIPC(hipMalloc((void**)&s.lat[i], lat_bytes));
   HIPC(hipMalloc((void**)&s.blocked, (size_t)s.plane));
@@ -223,6 +226,31 @@ int slab_upload(lbm_ctx* c, Slab& s, const int* obstacles, const float* cells) {
   return LBM_OK;
 }
 
+// Default kernel flavour for a context (overridable: LBM_VECTOR_WIDTH / LBM_KERNEL_VARIANT
+// env, or lbm_set_option).  Measured on MI355X (tools/kbench, profiles/):
+//   * lattices that stay resident in the 256 MiB Infinity Cache (both lattices of 1024^2
+//     are 75 MB): 4 cells per thread, default cache policy -- nontemporal accesses bypass
+//     the cache the next step would hit (12.9 us vs 15-19 us per step);
+//   * lattices streamed from HBM (8192^2: 4.8 GB): 2 cells per thread (8 waves per SIMD)
+//     with nontemporal loads and stores (862 us vs 887-940 us per step).
+// v_rcp_f32 / v_sqrt_f32 (1 ulp) replace the IEEE divide and sqrt sequences in both.
+void pick_defaults(lbm_ctx* c) {
+  double bytes = 0;
+  for (auto& s : c->slabs) bytes += 2.0 * 9 * sizeof(float) * (double)s.plane;
+  const bool cache_resident = bytes / (double)c->slabs.size() <= 160.0 * 1024 * 1024;
+  const int nx = c->p.nx;
+  if (cache_resident) {
+    c->V = pick_vector_width(nx);
+    c->variant = lbm::kFastMath;
+  } else {
+    c->V = (nx % 2 == 0 && nx >= 4) ? 2 : 1;
+    c->variant = lbm::kFastMath | lbm::kNtLoad | lbm::kNtStore;
+  }
+  const char* e;
+  if ((e = getenv("LBM_VECTOR_WIDTH"))) c->V = pick_vector_width(nx);
+  if ((e = getenv("LBM_KERNEL_VARIANT"))) c->variant = atol(e) & 7;
+}
+
 void slab_free(Slab& s) {
   (void)hipSetDevice(s.dev);
   for (int i = 0; i < 2; ++i) {
@@ -259,11 +287,26 @@ long count_fluid(const int* obstacles, long n) {
 }
 
 // Launches one sweep over rows y_begin + i*y_stride of slab s.
-template <int V>
-void launch_sweep_v(const lbm::SweepArgs& a, hipStream_t st) {
+template <int V, int MODE>
+void launch_sweep_vm(const lbm::SweepArgs& a, hipStream_t st) {
   const long threads = (long)a.y_count * (a.nx / V);
   const int grid = cdiv(threads, lbm::kBlock);
-  hipLaunchKernelGGL(lbm::lbm_sweep<V>, dim3(grid), dim3(lbm::kBlock), 0, st, a);
+  hipLaunchKernelGGL((lbm::lbm_sweep<V, MODE>), dim3(grid), dim3(lbm::kBlock), 0, st, a);
+}
+
+// variant = lbm::kFastMath | kNtStore | kNtLoad bits (option "kernel_variant")
+template <int V>
+void launch_sweep_v(const lbm::SweepArgs& a, hipStream_t st, long variant) {
+  switch (variant & 7) {
+    case 0: launch_sweep_vm<V, 0>(a, st); break;
+    case 1: launch_sweep_vm<V, 1>(a, st); break;
+    case 2: launch_sweep_vm<V, 2>(a, st); break;
+    case 3: launch_sweep_vm<V, 3>(a, st); break;
+    case 4: launch_sweep_vm<V, 4>(a, st); break;
+    case 5: launch_sweep_vm<V, 5>(a, st); break;
+    case 6: launch_sweep_vm<V, 6>(a, st); break;
+    default: launch_sweep_vm<V, 7>(a, st); break;
+  }
 }
 
 int sweep_blocks(const lbm_ctx* c, int y_count) {
@@ -272,9 +315,9 @@ int sweep_blocks(const lbm_ctx* c, int y_count) {
 
 void launch_sweep(const lbm_ctx* c, const lbm::SweepArgs& a, hipStream_t st) {
   switch (c->V) {
-    case 4: launch_sweep_v<4>(a, st); break;
-    case 2: launch_sweep_v<2>(a, st); break;
-    default: launch_sweep_v<1>(a, st); break;
+    case 4: launch_sweep_v<4>(a, st, c->variant); break;
+    case 2: launch_sweep_v<2>(a, st, c->variant); break;
+    default: launch_sweep_v<1>(a, st, c->variant); break;
   }
 }
 
@@ -340,6 +383,7 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
     rc = slab_upload(c, s, obstacles, cells);
     if (rc) return rc;
   }
+  pick_defaults(c);
   return LBM_OK;
 }
 
@@ -381,7 +425,6 @@ extern "C" int lbm_create(const lbm_param* params, const int* obstacles, const f
   lbm_ctx* c = new lbm_ctx();
   c->p = *params;
   c->nranks = nslabs;
-  c->V = pick_vector_width(params->nx);
   const char* force = getenv("LBM_FORCE_EXCHANGE");
   if (nslabs == 1 && !(force && atoi(force)))
     c->exchange = 0;
@@ -438,7 +481,6 @@ extern "C" int lbm_create_rank(const lbm_param* params, const int* obstacles, co
   c->rank_mode = true;
   c->rank = rank;
   c->nranks = nranks;
-  c->V = pick_vector_width(params->nx);
   c->exchange = exchanging ? LBM_EXCHANGE_RCCL : 0;
   c->tot_fluid = count_fluid(obstacles, (long)params->nx * params->ny);
   c->slabs.resize(1);
@@ -746,13 +788,18 @@ extern "C" int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     c->V = (int)value;
     return LBM_OK;
   }
-  if (!strcmp(key, "kernel_variant")) { c->variant = value; return LBM_OK; }
+  if (!strcmp(key, "kernel_variant")) {
+    if (value < 0 || value > 7) return fail(LBM_EINVAL, "kernel_variant must be in [0, 7]");
+    c->variant = value;
+    return LBM_OK;
+  }
   return fail(LBM_EINVAL, "unknown option %s", key);
 }
 
 extern "C" int lbm_get_info(const lbm_ctx* c, const char* key, double* value) {
   if (!c || !key || !value) return fail(LBM_EINVAL, "NULL argument");
   if (!strcmp(key, "vector_width")) { *value = c->V; return LBM_OK; }
+  if (!strcmp(key, "kernel_variant")) { *value = (double)c->variant; return LBM_OK; }
   if (!strcmp(key, "fluid_cells")) { *value = (double)c->tot_fluid; return LBM_OK; }
   if (!strcmp(key, "exchange")) { *value = c->exchange; return LBM_OK; }
   if (!strcmp(key, "pitch")) { *value = c->slabs[0].pitch; return LBM_OK; }

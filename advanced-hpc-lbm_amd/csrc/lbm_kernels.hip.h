@@ -84,12 +84,27 @@ __device__ __forceinline__ T block_sum(T v, T* red) {
 // c_sq = 1/3 folded into the constants: 1/c_sq = 3, 1/(2 c_sq^2) = 4.5,
 // 1/(2 c_sq) = 1.5, and one reciprocal of the density shared by both
 // velocity components (the reference's own -Ofast build does the same).
+// Kernel mode bits (template parameter MODE of lbm_sweep).
+constexpr int kFastMath = 1;   // v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of the IEEE sequences
+constexpr int kNtStore = 2;    // nontemporal stores of the destination lattice
+constexpr int kNtLoad = 4;     // nontemporal loads of the source lattice
+constexpr int kBenchNoMath = 8;        // tools/kbench only: pull + store, no collision (wrong results)
+constexpr int kBenchAlignedOnly = 16;  // tools/kbench only: unshifted loads everywhere (wrong results)
+
+template <bool FAST> __device__ __forceinline__ float recip(float x) {
+  if constexpr (FAST) return __builtin_amdgcn_rcpf(x); else return 1.0f / x;
+}
+template <bool FAST> __device__ __forceinline__ float root(float x) {
+  if constexpr (FAST) return __builtin_amdgcn_sqrtf(x); else return sqrtf(x);
+}
+
+template <bool FAST>
 __device__ __forceinline__ float collide_cell(float (&p)[9], bool is_blocked, float omega) {
   const float w0 = 4.f / 9.f, w1 = 1.f / 9.f, w2 = 1.f / 36.f;
   float rho = p[0];
   rho += p[1]; rho += p[2]; rho += p[3]; rho += p[4];
   rho += p[5]; rho += p[6]; rho += p[7]; rho += p[8];
-  const float inv = 1.0f / rho;
+  const float inv = recip<FAST>(rho);
   const float ux = (p[1] + p[5] + p[8] - (p[3] + p[6] + p[7])) * inv;
   const float uy = (p[2] + p[5] + p[6] - (p[4] + p[7] + p[8])) * inv;
   const float usq = ux * ux + uy * uy;
@@ -113,10 +128,10 @@ __device__ __forceinline__ float collide_cell(float (&p)[9], bool is_blocked, fl
   float rho2 = t[0];
 #pragma unroll
   for (int k = 1; k < 9; ++k) rho2 += t[k];
-  const float inv2 = 1.0f / rho2;
+  const float inv2 = recip<FAST>(rho2);
   const float vx = (t[1] + t[5] + t[8] - (t[3] + t[6] + t[7])) * inv2;
   const float vy = (t[2] + t[5] + t[6] - (t[4] + t[7] + t[8])) * inv2;
-  const float speed = sqrtf(vx * vx + vy * vy);
+  const float speed = root<FAST>(vx * vx + vy * vy);
   // blocked cell: mirrored pulled values instead, no contribution
   const float b1 = p[3], b2 = p[4], b3 = p[1], b4 = p[2], b5 = p[7], b6 = p[8], b7 = p[5], b8 = p[6];
   p[0] = is_blocked ? p[0] : t[0];
@@ -144,30 +159,37 @@ typedef float f4a __attribute__((ext_vector_type(4), aligned(16)));
 typedef float f2a __attribute__((ext_vector_type(2), aligned(8)));
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
+template <bool NT, typename T> __device__ __forceinline__ T ldg(const T* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
+}
+template <bool NT, typename T> __device__ __forceinline__ void stg(T* p, const T& v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
 // V consecutive values of a row, shifted by one cell to the west / east, with
 // the periodic wrap of the reference (x_w = ii ? ii-1 : nx-1, x_e = (ii+1)%nx;
-// d2q9-bgk.c:2133-2135).
-template <int V> struct Row;
+// d2q9-bgk.c:2133-2135).  NTL / NTS: nontemporal loads / stores.
+template <int V, bool NTL, bool NTS> struct Row;
 
-template <> struct Row<1> {
-  static __device__ __forceinline__ void ld(const float* r, int x0, float (&o)[1]) { o[0] = r[x0]; }
+template <bool NTL, bool NTS> struct Row<1, NTL, NTS> {
+  static __device__ __forceinline__ void ld(const float* r, int x0, float (&o)[1]) { o[0] = ldg<NTL>(r + x0); }
   static __device__ __forceinline__ void ld_w(const float* r, int x0, int nx, float (&o)[1]) {
-    o[0] = r[x0 ? x0 - 1 : nx - 1];
+    o[0] = ldg<NTL>(r + (x0 ? x0 - 1 : nx - 1));
   }
   static __device__ __forceinline__ void ld_e(const float* r, int x0, int nx, float (&o)[1]) {
-    o[0] = r[x0 + 1 == nx ? 0 : x0 + 1];
+    o[0] = ldg<NTL>(r + (x0 + 1 == nx ? 0 : x0 + 1));
   }
-  static __device__ __forceinline__ void st(float* r, int x0, const float (&v)[1]) { r[x0] = v[0]; }
+  static __device__ __forceinline__ void st(float* r, int x0, const float (&v)[1]) { stg<NTS>(r + x0, v[0]); }
 };
 
-template <> struct Row<2> {
+template <bool NTL, bool NTS> struct Row<2, NTL, NTS> {
   static __device__ __forceinline__ void ld(const float* r, int x0, float (&o)[2]) {
-    const f2a v = *reinterpret_cast<const f2a*>(r + x0);
+    const f2a v = ldg<NTL>(reinterpret_cast<const f2a*>(r + x0));
     o[0] = v.x; o[1] = v.y;
   }
   static __device__ __forceinline__ void ld_w(const float* r, int x0, int nx, float (&o)[2]) {
     if (x0 > 0) {
-      const f2u v = *reinterpret_cast<const f2u*>(r + x0 - 1);
+      const f2u v = ldg<NTL>(reinterpret_cast<const f2u*>(r + x0 - 1));
       o[0] = v.x; o[1] = v.y;
     } else {
       o[0] = r[nx - 1]; o[1] = r[0];
@@ -175,7 +197,7 @@ template <> struct Row<2> {
   }
   static __device__ __forceinline__ void ld_e(const float* r, int x0, int nx, float (&o)[2]) {
     if (x0 + 2 < nx) {
-      const f2u v = *reinterpret_cast<const f2u*>(r + x0 + 1);
+      const f2u v = ldg<NTL>(reinterpret_cast<const f2u*>(r + x0 + 1));
       o[0] = v.x; o[1] = v.y;
     } else {
       o[0] = r[x0 + 1]; o[1] = r[0];
@@ -183,18 +205,18 @@ template <> struct Row<2> {
   }
   static __device__ __forceinline__ void st(float* r, int x0, const float (&v)[2]) {
     f2a o; o.x = v[0]; o.y = v[1];
-    *reinterpret_cast<f2a*>(r + x0) = o;
+    stg<NTS>(reinterpret_cast<f2a*>(r + x0), o);
   }
 };
 
-template <> struct Row<4> {
+template <bool NTL, bool NTS> struct Row<4, NTL, NTS> {
   static __device__ __forceinline__ void ld(const float* r, int x0, float (&o)[4]) {
-    const f4a v = *reinterpret_cast<const f4a*>(r + x0);
+    const f4a v = ldg<NTL>(reinterpret_cast<const f4a*>(r + x0));
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
   }
   static __device__ __forceinline__ void ld_w(const float* r, int x0, int nx, float (&o)[4]) {
     if (x0 > 0) {
-      const f4u v = *reinterpret_cast<const f4u*>(r + x0 - 1);
+      const f4u v = ldg<NTL>(reinterpret_cast<const f4u*>(r + x0 - 1));
       o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
     } else {
       o[0] = r[nx - 1]; o[1] = r[0]; o[2] = r[1]; o[3] = r[2];
@@ -202,7 +224,7 @@ template <> struct Row<4> {
   }
   static __device__ __forceinline__ void ld_e(const float* r, int x0, int nx, float (&o)[4]) {
     if (x0 + 4 < nx) {
-      const f4u v = *reinterpret_cast<const f4u*>(r + x0 + 1);
+      const f4u v = ldg<NTL>(reinterpret_cast<const f4u*>(r + x0 + 1));
       o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
     } else {
       o[0] = r[x0 + 1]; o[1] = r[x0 + 2]; o[2] = r[x0 + 3]; o[3] = r[0];
@@ -210,13 +232,16 @@ template <> struct Row<4> {
   }
   static __device__ __forceinline__ void st(float* r, int x0, const float (&v)[4]) {
     f4a o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-    *reinterpret_cast<f4a*>(r + x0) = o;
+    stg<NTS>(reinterpret_cast<f4a*>(r + x0), o);
   }
 };
 
 // The fused step.  Requires nx % V == 0 (host picks V); any nyl >= 1.
-template <int V>
+template <int V, int MODE = 0>
 __global__ __launch_bounds__(kBlock) void lbm_sweep(const SweepArgs a) {
+  constexpr bool FAST = (MODE & kFastMath) != 0;
+  using R = Row<V, (MODE & kNtLoad) != 0, (MODE & kNtStore) != 0>;
+  using RS = Row<V, false, false>;   // halo send buffers: plain stores
   __shared__ float red_f[kBlock / 64];
   __shared__ double red_d[kBlock / 64];
 
@@ -254,15 +279,20 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep(const SweepArgs a) {
     const float* r8 = at_n ? a.north8 : s + 8 * P + rc + a.pitch;
 
     float q[9][V];
-    Row<V>::ld(r0, x0, q[0]);
-    Row<V>::ld_w(r1, x0, a.nx, q[1]);
-    Row<V>::ld(r2, x0, q[2]);
-    Row<V>::ld_e(r3, x0, a.nx, q[3]);
-    Row<V>::ld(r4, x0, q[4]);
-    Row<V>::ld_w(r5, x0, a.nx, q[5]);
-    Row<V>::ld_e(r6, x0, a.nx, q[6]);
-    Row<V>::ld_e(r7, x0, a.nx, q[7]);
-    Row<V>::ld_w(r8, x0, a.nx, q[8]);
+    if constexpr ((MODE & kBenchAlignedOnly) != 0) {
+      R::ld(r0, x0, q[0]); R::ld(r1, x0, q[1]); R::ld(r2, x0, q[2]); R::ld(r3, x0, q[3]); R::ld(r4, x0, q[4]);
+      R::ld(r5, x0, q[5]); R::ld(r6, x0, q[6]); R::ld(r7, x0, q[7]); R::ld(r8, x0, q[8]);
+    } else {
+      R::ld(r0, x0, q[0]);
+      R::ld_w(r1, x0, a.nx, q[1]);
+      R::ld(r2, x0, q[2]);
+      R::ld_e(r3, x0, a.nx, q[3]);
+      R::ld(r4, x0, q[4]);
+      R::ld_w(r5, x0, a.nx, q[5]);
+      R::ld_e(r6, x0, a.nx, q[6]);
+      R::ld_e(r7, x0, a.nx, q[7]);
+      R::ld_w(r8, x0, a.nx, q[8]);
+    }
 
     bool blk[V];
     if constexpr (V == 4) {
@@ -281,26 +311,30 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep(const SweepArgs a) {
       float p[9];
 #pragma unroll
       for (int k = 0; k < 9; ++k) p[k] = q[k][v];
-      local += collide_cell(p, blk[v], a.omega);
-      if (do_accel) accelerate_cell(p, blk[v], a.a1, a.a2);
+      if constexpr ((MODE & kBenchNoMath) == 0) {
+        local += collide_cell<FAST>(p, blk[v], a.omega);
+        if (do_accel) accelerate_cell(p, blk[v], a.a1, a.a2);
+      } else {
+        local += blk[v] ? 0.f : p[0];
+      }
 #pragma unroll
       for (int k = 0; k < 9; ++k) q[k][v] = p[k];
     }
 
     float* d = a.dst + rc;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Row<V>::st(d + k * P, x0, q[k]);
+    for (int k = 0; k < 9; ++k) R::st(d + k * P, x0, q[k]);
 
     // packed halo rows for the neighbouring slabs (multi-slab runs only)
     if (at_s && a.send_south != nullptr) {
-      Row<V>::st(a.send_south, x0, q[4]);
-      Row<V>::st(a.send_south + a.nx, x0, q[7]);
-      Row<V>::st(a.send_south + 2 * a.nx, x0, q[8]);
+      RS::st(a.send_south, x0, q[4]);
+      RS::st(a.send_south + a.nx, x0, q[7]);
+      RS::st(a.send_south + 2 * a.nx, x0, q[8]);
     }
     if (at_n && a.send_north != nullptr) {
-      Row<V>::st(a.send_north, x0, q[2]);
-      Row<V>::st(a.send_north + a.nx, x0, q[5]);
-      Row<V>::st(a.send_north + 2 * a.nx, x0, q[6]);
+      RS::st(a.send_north, x0, q[2]);
+      RS::st(a.send_north + a.nx, x0, q[5]);
+      RS::st(a.send_north + 2 * a.nx, x0, q[6]);
     }
   }
 

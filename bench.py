@@ -41,13 +41,17 @@ BYTES_PER_LUP = 72.0     # 9 float32 reads + 9 float32 writes
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def wall_x(n: int) -> int:
+    return 2730 if n == 8192 else (341 * n) // 1024
+
+
 def synthetic_obstacles(n: int) -> np.ndarray:
     """BASELINE.json's synthetic deck: the 1024x1024 geometry scaled by n/1024 -- closed box
     plus a full-height wall at x = n/3 (2730 for 8192)."""
     ob = np.zeros((n, n), dtype=np.int32)
     ob[0, :] = ob[-1, :] = 1
     ob[:, 0] = ob[:, -1] = 1
-    ob[:, (341 * n) // 1024] = 1
+    ob[:, wall_x(n)] = 1
     return ob
 
 
@@ -63,7 +67,7 @@ def make_workload(name: str):
         n = int(m.group(1))
         p = L.Param(n, n, 1000, 10, 0.1, 0.01, 1.85)
         ob = synthetic_obstacles(n)
-        data = f"synthetic {n}x{n}: box walls + full-height wall at x={(341 * n) // 1024}, rest-equilibrium start"
+        data = f"synthetic {n}x{n}: box walls + full-height wall at x={wall_x(n)}, rest-equilibrium start"
     return p, ob, data
 
 
@@ -169,7 +173,7 @@ def main():
     ap.add_argument("--workload", default="1024x1024")
     ap.add_argument("--also", default="8192x8192", help="second workload reported under 'also' ('' to skip)")
     ap.add_argument("--also-steps", type=int, default=300)
-    ap.add_argument("--cpu-sample-steps", type=int, default=600, help="0 = skip the CPU baseline")
+    ap.add_argument("--cpu-sample-steps", type=int, default=1000, help="0 = skip the CPU baseline")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -117,7 +117,9 @@ def test_ragged_and_minimum_sizes(gpu, O, oracle, nx, ny):
     with L.Lattice(p, ob, c0) as lat:
         av = lat.run(6)
         st = lat.read_state()
-    assert np.all(np.abs(st - ref) <= 2e-5 * np.abs(ref))
+    # far-from-equilibrium random states: some relaxed values nearly cancel, so the bound is
+    # relative to the lattice scale as well as to the element
+    assert np.all(np.abs(st - ref) <= 2e-5 * np.abs(ref) + 2e-6 * np.abs(ref).max())
     assert np.allclose(av, av_o, rtol=2e-5, atol=0)
 
 
@@ -135,7 +137,7 @@ def test_all_cells_blocked_but_one_row(gpu, O, oracle):
     with L.Lattice(p, ob, c0) as lat:
         av = lat.run(4)
         st = lat.read_state()
-    assert np.all(np.abs(st - ref) <= 2e-5 * np.abs(ref))
+    assert np.all(np.abs(st - ref) <= 2e-5 * np.abs(ref) + 2e-6 * np.abs(ref).max())
     assert np.allclose(av, av_o, rtol=2e-5)
 
 

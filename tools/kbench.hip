@@ -19,7 +19,22 @@ struct Lat {
   float* lat[2]; uint8_t* blocked; float* partials[2];
 };
 
-template <int V>
+// ceiling reference: straight copy of the 9 planes, 16 B per lane, no stencil, no math
+__global__ __launch_bounds__(256) void copy9(const float* __restrict__ src, float* __restrict__ dst, long plane, long nvec) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec) return;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const lbm::f4a v = *reinterpret_cast<const lbm::f4a*>(src + k * plane + 4 * i);
+    *reinterpret_cast<lbm::f4a*>(dst + k * plane + 4 * i) = v;
+  }
+}
+static void launch_copy9(const Lat& L, int cur, int q, hipStream_t st, bool) {
+  const long nvec = (long)L.ny * L.pitch / 4;
+  hipLaunchKernelGGL(copy9, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, L.lat[cur], L.lat[cur ^ 1], L.plane, nvec);
+}
+
+template <int V, int MODE>
 static void launch(const Lat& L, int cur, int q, hipStream_t st, bool accel) {
   lbm::SweepArgs a{};
   a.src = L.lat[cur]; a.dst = L.lat[cur ^ 1];
@@ -35,7 +50,7 @@ static void launch(const Lat& L, int cur, int q, hipStream_t st, bool accel) {
   const int grid = (int)((threads + lbm::kBlock - 1) / lbm::kBlock);
   a.prev_partials = L.partials[q ^ 1]; a.prev_count = grid; a.prev_sum = (double*)(L.partials[0] + 0) ;
   a.prev_partials = nullptr;  // the fold is negligible; keep the A/B about the sweep itself
-  hipLaunchKernelGGL(lbm::lbm_sweep<V>, dim3(grid), dim3(lbm::kBlock), 0, st, a);
+  hipLaunchKernelGGL((lbm::lbm_sweep<V, MODE>), dim3(grid), dim3(lbm::kBlock), 0, st, a);
 }
 
 int main(int argc, char** argv) {
@@ -61,7 +76,18 @@ int main(int argc, char** argv) {
   }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   struct Var { const char* name; void (*fn)(const Lat&, int, int, hipStream_t, bool); };
-  const Var vars[] = {{"V=4", launch<4>}, {"V=2", launch<2>}, {"V=1", launch<1>}};
+  using namespace lbm;
+  const Var vars[] = {
+      {"copy9", launch_copy9},
+      {"V4", launch<4, 0>}, {"V4 fast", launch<4, kFastMath>}, {"V4 fast nts", launch<4, kFastMath | kNtStore>},
+      {"V4 fast ntl", launch<4, kFastMath | kNtLoad>}, {"V4 fast ntl nts", launch<4, kFastMath | kNtLoad | kNtStore>},
+      {"V2", launch<2, 0>}, {"V2 fast", launch<2, kFastMath>}, {"V2 fast nts", launch<2, kFastMath | kNtStore>},
+      {"V2 fast ntl", launch<2, kFastMath | kNtLoad>}, {"V2 fast ntl nts", launch<2, kFastMath | kNtLoad | kNtStore>},
+      {"V1 fast", launch<1, kFastMath>},
+      {"V4 nomath", launch<4, kBenchNoMath>}, {"V4 fast aligned", launch<4, kFastMath | kBenchAlignedOnly>},
+      {"V4 nomath aligned", launch<4, kBenchNoMath | kBenchAlignedOnly>},
+      {"V2 nomath", launch<2, kBenchNoMath>}, {"V2 fast aligned", launch<2, kFastMath | kBenchAlignedOnly>},
+  };
   const int nv = sizeof(vars) / sizeof(vars[0]);
   std::vector<std::vector<double>> us(nv);
   int cur = 0;
@@ -80,7 +106,7 @@ int main(int argc, char** argv) {
     std::sort(us[v].begin(), us[v].end());
     const double med = us[v][us[v].size() / 2], mn = us[v][0];
     const double mlups = (double)n * n / med;
-    printf("%-12s median %9.2f us  min %9.2f us  %9.0f MLUPS  %7.0f GB/s  frac %.3f\n", vars[v].name, med, mn,
+    printf("%-18s median %9.2f us  min %9.2f us  %9.0f MLUPS  %7.0f GB/s  frac %.3f\n", vars[v].name, med, mn,
            mlups, mlups * 72 / 1e3, mlups * 72 / 8e6);
   }
   return 0;
