@@ -138,8 +138,12 @@ struct lbm_ctx {
   long tot_fluid = 0;          // non-blocked cells of the GLOBAL lattice
   int V = 1;                   // cells per thread
   long variant = 0;
+  int time_block = 1;          // 2: fuse pairs of steps through LDS (lbm_sweep2) where eligible
   double gpu_ms = 0.0, wall_ms = 0.0;
 };
+
+// tile of the two-step kernel
+constexpr int kT2X = 64, kT2Y = 16;
 
 namespace {
 
@@ -246,9 +250,32 @@ void pick_defaults(lbm_ctx* c) {
     c->V = (nx % 2 == 0 && nx >= 4) ? 2 : 1;
     c->variant = lbm::kFastMath | lbm::kNtLoad | lbm::kNtStore;
   }
+  // Two steps per pass through LDS: 1.4x (1024^2) to 1.65x (8192^2) over the single-step
+  // sweep (kbench); nontemporal stores only pay off when the lattice streams from HBM.
+  c->time_block = 2;
   const char* e;
   if ((e = getenv("LBM_VECTOR_WIDTH"))) c->V = pick_vector_width(nx);
   if ((e = getenv("LBM_KERNEL_VARIANT"))) c->variant = atol(e) & 7;
+  if ((e = getenv("LBM_TIME_BLOCK"))) c->time_block = atoi(e) == 2 ? 2 : 1;
+}
+
+// The two-step kernel covers whole tiles of one periodic slab.
+bool t2_eligible(const lbm_ctx* c) {
+  return c->time_block == 2 && c->exchange == 0 && c->slabs.size() == 1 && c->p.nx % kT2X == 0 &&
+         c->p.ny % kT2Y == 0;
+}
+
+template <int MODE>
+void launch_sweep2_m(const lbm::Sweep2Args& a, int grid, hipStream_t st) {
+  hipLaunchKernelGGL((lbm::lbm_sweep2<kT2X, kT2Y, MODE>), dim3(grid), dim3(lbm::kBlock), 0, st, a);
+}
+
+void launch_sweep2(const lbm_ctx* c, const lbm::Sweep2Args& a, int grid, hipStream_t st) {
+  // cache-resident lattices: default policy; streamed lattices: nontemporal stores (kbench)
+  const bool nts = (c->variant & lbm::kNtStore) != 0;
+  const bool fast = (c->variant & lbm::kFastMath) != 0;
+  if (fast) { if (nts) launch_sweep2_m<lbm::kFastMath | lbm::kNtStore>(a, grid, st); else launch_sweep2_m<lbm::kFastMath>(a, grid, st); }
+  else { if (nts) launch_sweep2_m<lbm::kNtStore>(a, grid, st); else launch_sweep2_m<0>(a, grid, st); }
 }
 
 void slab_free(Slab& s) {
@@ -552,7 +579,36 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
   }
 
   // ---- the step loop (reference d2q9-bgk.c:180-201); no host sync inside
-  for (int tt = 0; tt < nsteps; ++tt) {
+  int tt0 = 0;
+  if (t2_eligible(c) && nsteps >= 2) {
+    // pairs of steps fused through LDS; a trailing odd step takes the single-step path below
+    Slab& s = c->slabs[0];
+    HIPC(hipSetDevice(s.dev));
+    const int npairs = nsteps / 2;
+    const int nblk = (nx / kT2X) * (c->p.ny / kT2Y);
+    for (int j = 0; j < npairs; ++j) {
+      const int q = j & 1;
+      lbm::Sweep2Args a;
+      a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
+      a.plane = s.plane; a.pitch = s.pitch; a.nx = nx; a.ny = s.nyl;
+      a.blocked = s.blocked; a.omega = c->p.omega;
+      a.accel_row = s.accel_row;
+      a.accel_out = (2 * j + 2 < nsteps) ? 1 : 0;
+      a.a1 = a1; a.a2 = a2;
+      a.partials1 = s.partials[q]; a.partials2 = s.partials[q] + nblk;
+      a.prev1 = a.prev2 = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
+      if (j > 0) { a.prev1 = s.partials[q ^ 1]; a.prev2 = s.partials[q ^ 1] + nblk; a.prev_count = nblk; a.prev_sum = s.sums + 2 * (j - 1); }
+      launch_sweep2(c, a, nblk, s.sc);
+      HIPC(hipGetLastError());
+      c->cur ^= 1;
+    }
+    const int ql2 = (npairs - 1) & 1;
+    hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql2], nblk, s.sums + 2 * (npairs - 1));
+    hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql2] + nblk, nblk, s.sums + 2 * (npairs - 1) + 1);
+    HIPC(hipGetLastError());
+    tt0 = 2 * npairs;
+  }
+  for (int tt = tt0; tt < nsteps; ++tt) {
     const int q = tt & 1, qp = q ^ 1;
     const bool last = (tt == nsteps - 1);
     for (auto& s : c->slabs) {
@@ -575,7 +631,7 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
         a.send_south = a.send_north = nullptr;
         a.y_begin = 0; a.y_count = s.nyl; a.y_stride = 1;
         const int nb = sweep_blocks(c, a.y_count);
-        if (tt > 0) { a.prev_partials = s.partials[qp]; a.prev_count = nb; a.prev_sum = s.sums + (tt - 1); }
+        if (tt > tt0) { a.prev_partials = s.partials[qp]; a.prev_count = nb; a.prev_sum = s.sums + (tt - 1); }
         launch_sweep(c, a, s.sc);
         HIPC(hipGetLastError());
       } else {
@@ -587,7 +643,7 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
         a.y_begin = 0; a.y_count = nb_rows; a.y_stride = s.nyl >= 2 ? s.nyl - 1 : 1;
         const int nbb = sweep_blocks(c, nb_rows);
         const int nbi = s.nyl > 2 ? sweep_blocks(c, s.nyl - 2) : 0;
-        if (tt > 0) { a.prev_partials = s.partials[qp]; a.prev_count = nbb + nbi; a.prev_sum = s.sums + (tt - 1); }
+        if (tt > tt0) { a.prev_partials = s.partials[qp]; a.prev_count = nbb + nbi; a.prev_sum = s.sums + (tt - 1); }
         HIPC(hipStreamWaitEvent(s.sc, s.ev_recv[qp], 0));
         launch_sweep(c, a, s.sc);
         HIPC(hipGetLastError());
@@ -623,11 +679,13 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
   const int ql = (nsteps - 1) & 1;
   for (auto& s : c->slabs) {
     HIPC(hipSetDevice(s.dev));
-    int count;
-    if (!ex) count = sweep_blocks(c, s.nyl);
-    else count = sweep_blocks(c, s.nyl >= 2 ? 2 : 1) + (s.nyl > 2 ? sweep_blocks(c, s.nyl - 2) : 0);
-    hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql], count, s.sums + (nsteps - 1));
-    HIPC(hipGetLastError());
+    if (tt0 < nsteps) {  // the last step ran on the single-step path: fold its partials
+      int count;
+      if (!ex) count = sweep_blocks(c, s.nyl);
+      else count = sweep_blocks(c, s.nyl >= 2 ? 2 : 1) + (s.nyl > 2 ? sweep_blocks(c, s.nyl - 2) : 0);
+      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql], count, s.sums + (nsteps - 1));
+      HIPC(hipGetLastError());
+    }
     HIPC(hipEventRecord(s.ev_t1, s.sc));
     if (ex) HIPC(hipStreamWaitEvent(s.sc, s.ev_recv[ql], 0));  // drain the last exchange
   }
@@ -788,6 +846,11 @@ extern "C" int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     c->V = (int)value;
     return LBM_OK;
   }
+  if (!strcmp(key, "time_block")) {
+    if (value != 1 && value != 2) return fail(LBM_EINVAL, "time_block must be 1 or 2");
+    c->time_block = (int)value;
+    return LBM_OK;
+  }
   if (!strcmp(key, "kernel_variant")) {
     if (value < 0 || value > 7) return fail(LBM_EINVAL, "kernel_variant must be in [0, 7]");
     c->variant = value;
@@ -800,6 +863,8 @@ extern "C" int lbm_get_info(const lbm_ctx* c, const char* key, double* value) {
   if (!c || !key || !value) return fail(LBM_EINVAL, "NULL argument");
   if (!strcmp(key, "vector_width")) { *value = c->V; return LBM_OK; }
   if (!strcmp(key, "kernel_variant")) { *value = (double)c->variant; return LBM_OK; }
+  if (!strcmp(key, "time_block")) { *value = c->time_block; return LBM_OK; }
+  if (!strcmp(key, "time_block_active")) { *value = t2_eligible(c) ? 2 : 1; return LBM_OK; }
   if (!strcmp(key, "fluid_cells")) { *value = (double)c->tot_fluid; return LBM_OK; }
   if (!strcmp(key, "exchange")) { *value = c->exchange; return LBM_OK; }
   if (!strcmp(key, "pitch")) { *value = c->slabs[0].pitch; return LBM_OK; }

@@ -342,6 +342,177 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep(const SweepArgs a) {
   if (threadIdx.x == 0) a.partials[blockIdx.x] = bs;
 }
 
+// ---------------------------------------------------------------------------
+// Two time steps in one pass (temporal blocking through LDS).
+//
+// A block owns a TX x TY tile of the lattice at step t+2.  Phase A computes step
+// t+1 on the tile plus a one-cell ring ((TX+2) x (TY+2) cells, the ring is
+// recomputed by the neighbouring tiles too) straight from the source lattice in
+// HBM and parks the nine planes in LDS; phase B pulls step t+2 for the tile out
+// of LDS and writes it to the destination lattice.  HBM traffic per TWO lattice
+// updates: 36 B written + 36 B x (TX+2)(TY+2)/(TX TY) read (1.16x for 64 x 16)
+// instead of 144 B, so the sweep runs above the single-step 72 B/LUP roofline.
+//
+// Each LDS plane is stored shifted by (4 - s_k) % 4 columns, s_k = the column
+// offset phase B pulls plane k with (1 for planes 0,2,4; 0 for 1,5,8; 2 for
+// 3,6,7), so that every phase-B read is one aligned ds_read_b128 per plane.
+// Per-cell arithmetic is collide_cell / accelerate_cell, exactly as in
+// lbm_sweep: the accelerate phase of step t+2 is applied to the step-t+1 values
+// of row ny-2 as they go into LDS (ring cells included), that of step t+3 to the
+// outputs unless the run ends there.  Speed sums: step t+1 counts the tile's own
+// cells only (not the ring), step t+2 the tile.
+struct Sweep2Args {
+  const float* src;
+  float* dst;
+  long plane;
+  int pitch, nx, ny;           // one slab, periodic in both axes
+  const uint8_t* blocked;
+  float omega;
+  int accel_row;               // ny-2
+  int accel_out;               // apply the accelerate phase to the outputs (0 on the last pair)
+  float a1, a2;
+  float* partials1;            // per block: speed sum of step t+1
+  float* partials2;            // per block: speed sum of step t+2
+  const float* prev1;          // previous pair's partials, folded by block 0 (or nullptr)
+  const float* prev2;
+  int prev_count;
+  double* prev_sum;            // prev_sum[0], prev_sum[1]
+};
+
+template <int TX, int TY, int MODE>
+__global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
+  static_assert((TX / 4) * TY == kBlock, "phase B: one thread per 4 cells of the tile");
+  constexpr bool FAST = (MODE & kFastMath) != 0;
+  constexpr bool NTL = (MODE & kNtLoad) != 0, NTS = (MODE & kNtStore) != 0;
+  constexpr int IW = TX + 2, IH = TY + 2;          // step-t+1 region: tile + ring
+  constexpr int LW = (IW + 3 + 3) / 4 * 4;         // LDS row stride (floats), room for the shift
+  constexpr int NA = (IW * IH + kBlock - 1) / kBlock;
+  __shared__ __attribute__((aligned(16))) float lds[9][IH][LW];
+  __shared__ float red_f[kBlock / 64];
+  __shared__ float red_g[kBlock / 64];
+  __shared__ double red_d[kBlock / 64];
+
+  if (blockIdx.x == 0 && a.prev1 != nullptr) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < a.prev_count; i += kBlock) { s1 += (double)a.prev1[i]; s2 += (double)a.prev2[i]; }
+    s1 = block_sum<double>(s1, red_d);
+    __syncthreads();
+    s2 = block_sum<double>(s2, red_d);
+    if (threadIdx.x == 0) { a.prev_sum[0] = s1; a.prev_sum[1] = s2; }
+    __syncthreads();
+  }
+
+  // XCD-aware tile order: block ids are dealt round-robin over the 8 XCDs, so give each XCD a
+  // contiguous run of tiles -- x-neighbours, which share ring columns, then share an L2.
+  const int ntx = a.nx / TX;
+  const int nblk = gridDim.x;
+  int b = blockIdx.x;
+  if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);
+  const int by = b / ntx, bx = b - by * ntx;
+  const int X0 = bx * TX, Y0 = by * TY;
+  const long P = a.plane;
+  const float* s = a.src;
+
+  // ---- phase A: step t+1 on the (TX+2) x (TY+2) region -> LDS
+  float q[NA][9];
+  bool blk[NA];
+  int cxs[NA], cys[NA];
+#pragma unroll
+  for (int m = 0; m < NA; ++m) {
+    const int idx = threadIdx.x + m * kBlock;
+    const int cy = idx / IW, cx = idx - cy * IW;
+    cxs[m] = cx; cys[m] = cy;
+    if (idx < IW * IH) {
+      int gx = X0 - 1 + cx; gx += (gx < 0) ? a.nx : 0; gx -= (gx >= a.nx) ? a.nx : 0;
+      int gy = Y0 - 1 + cy; gy += (gy < 0) ? a.ny : 0; gy -= (gy >= a.ny) ? a.ny : 0;
+      const int xw = gx ? gx - 1 : a.nx - 1, xe = (gx + 1 == a.nx) ? 0 : gx + 1;
+      const int ys = gy ? gy - 1 : a.ny - 1, yn = (gy + 1 == a.ny) ? 0 : gy + 1;
+      const long rc = (long)gy * a.pitch, rs = (long)ys * a.pitch, rn = (long)yn * a.pitch;
+      q[m][0] = ldg<NTL>(s + rc + gx);
+      q[m][1] = ldg<NTL>(s + P + rc + xw);
+      q[m][2] = ldg<NTL>(s + 2 * P + rs + gx);
+      q[m][3] = ldg<NTL>(s + 3 * P + rc + xe);
+      q[m][4] = ldg<NTL>(s + 4 * P + rn + gx);
+      q[m][5] = ldg<NTL>(s + 5 * P + rs + xw);
+      q[m][6] = ldg<NTL>(s + 6 * P + rs + xe);
+      q[m][7] = ldg<NTL>(s + 7 * P + rn + xe);
+      q[m][8] = ldg<NTL>(s + 8 * P + rn + xw);
+      blk[m] = a.blocked[rc + gx] != 0;
+      cys[m] = cy | (gy == a.accel_row ? 0x10000 : 0);
+    }
+  }
+  float sum1 = 0.f;
+#pragma unroll
+  for (int m = 0; m < NA; ++m) {
+    const int idx = threadIdx.x + m * kBlock;
+    if (idx < IW * IH) {
+      const int cx = cxs[m], cy = cys[m] & 0xffff;
+      float sp = collide_cell<FAST>(q[m], blk[m], a.omega);
+      if (cys[m] & 0x10000) accelerate_cell(q[m], blk[m], a.a1, a.a2);
+      const bool own = (cx >= 1) && (cx <= TX) && (cy >= 1) && (cy <= TY);
+      sum1 += own ? sp : 0.f;
+      lds[0][cy][cx + 3] = q[m][0];
+      lds[1][cy][cx + 0] = q[m][1];
+      lds[2][cy][cx + 3] = q[m][2];
+      lds[3][cy][cx + 2] = q[m][3];
+      lds[4][cy][cx + 3] = q[m][4];
+      lds[5][cy][cx + 0] = q[m][5];
+      lds[6][cy][cx + 2] = q[m][6];
+      lds[7][cy][cx + 2] = q[m][7];
+      lds[8][cy][cx + 0] = q[m][8];
+    }
+  }
+  __syncthreads();
+
+  // ---- phase B: step t+2 on the tile, pulled from LDS
+  const int tx = threadIdx.x % (TX / 4), ty = threadIdx.x / (TX / 4);
+  const int x = 4 * tx;
+  const int gy = Y0 + ty;
+  const long rc = (long)gy * a.pitch + X0 + x;
+  float o[9][4];
+  {
+    // intermediate column of tile cell x is x+1; plane k is pulled at column x+1 + (-1|0|+1)
+    // and stored shifted, so every row below starts at a 16-byte boundary: index x + 4 or x
+    const f4a v0 = *reinterpret_cast<const f4a*>(&lds[0][ty + 1][x + 4]);
+    const f4a v1 = *reinterpret_cast<const f4a*>(&lds[1][ty + 1][x]);
+    const f4a v2 = *reinterpret_cast<const f4a*>(&lds[2][ty][x + 4]);
+    const f4a v3 = *reinterpret_cast<const f4a*>(&lds[3][ty + 1][x + 4]);
+    const f4a v4 = *reinterpret_cast<const f4a*>(&lds[4][ty + 2][x + 4]);
+    const f4a v5 = *reinterpret_cast<const f4a*>(&lds[5][ty][x]);
+    const f4a v6 = *reinterpret_cast<const f4a*>(&lds[6][ty][x + 4]);
+    const f4a v7 = *reinterpret_cast<const f4a*>(&lds[7][ty + 2][x + 4]);
+    const f4a v8 = *reinterpret_cast<const f4a*>(&lds[8][ty + 2][x]);
+#define LBM_UNPACK(k, v) o[k][0] = v.x; o[k][1] = v.y; o[k][2] = v.z; o[k][3] = v.w;
+    LBM_UNPACK(0, v0) LBM_UNPACK(1, v1) LBM_UNPACK(2, v2) LBM_UNPACK(3, v3) LBM_UNPACK(4, v4)
+    LBM_UNPACK(5, v5) LBM_UNPACK(6, v6) LBM_UNPACK(7, v7) LBM_UNPACK(8, v8)
+#undef LBM_UNPACK
+  }
+  const uint32_t mb = *reinterpret_cast<const uint32_t*>(a.blocked + rc);
+  const bool ob[4] = {(mb & 0xffu) != 0, (mb & 0xff00u) != 0, (mb & 0xff0000u) != 0, (mb & 0xff000000u) != 0};
+  const bool do_accel = a.accel_out && (gy == a.accel_row);
+  float sum2 = 0.f;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    float p[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) p[k] = o[k][v];
+    sum2 += collide_cell<FAST>(p, ob[v], a.omega);
+    if (do_accel) accelerate_cell(p, ob[v], a.a1, a.a2);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k][v] = p[k];
+  }
+  float* d = a.dst + rc;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    f4a w; w.x = o[k][0]; w.y = o[k][1]; w.z = o[k][2]; w.w = o[k][3];
+    stg<NTS>(reinterpret_cast<f4a*>(d + k * P), w);
+  }
+
+  const float b1 = block_sum<float>(sum1, red_f);
+  const float b2 = block_sum<float>(sum2, red_g);
+  if (threadIdx.x == 0) { a.partials1[blockIdx.x] = b1; a.partials2[blockIdx.x] = b2; }
+}
+
 // Folds a step's block partials into its slab sum (after the last step of a run).
 __global__ __launch_bounds__(kBlock) void lbm_fold_partials(const float* partials, int count, double* out) {
   __shared__ double red_d[kBlock / 64];

@@ -106,6 +106,61 @@ def test_fifty_steps_against_float_oracle(gpu, O, oracle, deck):
         assert np.allclose(fs[..., :3], fo[..., :3], rtol=0, atol=2e-4 * np.abs(fo[..., 2]).max())
 
 
+@pytest.mark.parametrize("deck", DECKS)
+def test_two_step_kernel_equals_single_step_kernel(gpu, O, oracle, deck):
+    """lbm_sweep2 (two steps per pass through LDS, the default where the lattice tiles) against
+    lbm_sweep (one step per pass): same per-cell float operations, so the lattices must agree bit
+    for bit; odd step counts exercise the trailing single step, and both are checked against the
+    float oracle."""
+    L = gpu
+    pf, of = deck_paths(deck)
+    p = L.read_params(pf)
+    ob = L.read_obstacles(of, p)
+    op = O.read_params(pf)
+    n = 37
+    cells = oracle.init_cells(op, np.float32)
+    av_o = oracle.run(op, cells, ob, n)
+    res = {}
+    for tb in (1, 2):
+        for variant in (1, 3, 0):
+            with L.Lattice(p, ob) as lat:
+                lat.set_option("time_block", tb)
+                lat.set_option("kernel_variant", variant)
+                assert lat.info("time_block_active") == tb
+                av = np.concatenate([lat.run(n - 12), lat.run(12)])
+                res[(tb, variant)] = (av, lat.read_state())
+    for variant in (1, 3, 0):
+        (av1, st1), (av2, st2) = res[(1, variant)], res[(2, variant)]
+        assert np.array_equal(st1.view(np.uint32), st2.view(np.uint32)), variant
+        assert np.allclose(av1, av2, rtol=2e-6, atol=0)
+        assert np.abs(st2 - cells).max() <= 5e-5 * np.abs(cells).max()
+        assert np.allclose(av2, av_o, rtol=1e-4, atol=0)
+
+
+def test_two_step_kernel_known_answers(gpu, O):
+    """64x40 known answers of the reference need a lattice that tiles by 64x16: ny = 40 does
+    not, so the library must fall back to the single-step kernel there; a 64x48 random lattice
+    takes the two-step path and is checked against the float oracle."""
+    L = gpu
+    k, p, ob = _kat(L, O, "kat_64x40")
+    with L.Lattice(p, ob, k["cells0"]) as lat:
+        assert lat.info("time_block") == 2 and lat.info("time_block_active") == 1
+    rng = np.random.default_rng(99)
+    nx, ny = 64, 48
+    p = L.Param(nx, ny, 9, 3, 0.1, 0.02, 1.7)
+    op = O.OrcParam(nx, ny, 9, 3, float(p.density), float(p.accel), float(p.omega))
+    ob = (rng.random((ny, nx)) < 0.15).astype(np.int32)
+    c0 = (np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4) * 0.1 * (1 + 0.2 * (rng.random((ny, nx, 9)) - 0.5))).astype(np.float32)
+    ref = c0.copy()
+    av_o = O.Oracle("strict").run(op, ref, ob, 9)
+    with L.Lattice(p, ob, c0) as lat:
+        assert lat.info("time_block_active") == 2
+        av = lat.run(9)
+        st = lat.read_state()
+    assert np.all(np.abs(st - ref) <= 2e-5 * np.abs(ref))
+    assert np.allclose(av, av_o, rtol=2e-5, atol=0)
+
+
 @pytest.mark.parametrize("nx,ny", [(30, 17), (33, 9), (2, 2), (5, 3), (64, 2), (260, 11)])
 def test_ragged_and_minimum_sizes(gpu, O, oracle, nx, ny):
     """Widths that force the 2- and 1-cell-per-thread kernels, rows shorter than a wave,

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -53,6 +54,54 @@ static void launch(const Lat& L, int cur, int q, hipStream_t st, bool accel) {
   hipLaunchKernelGGL((lbm::lbm_sweep<V, MODE>), dim3(grid), dim3(lbm::kBlock), 0, st, a);
 }
 
+template <int TX, int TY, int MODE>
+static void launch2(const Lat& L, int cur, int q, hipStream_t st, bool accel) {
+  lbm::Sweep2Args a{};
+  a.src = L.lat[cur]; a.dst = L.lat[cur ^ 1];
+  a.plane = L.plane; a.pitch = L.pitch; a.nx = L.nx; a.ny = L.ny;
+  a.blocked = L.blocked; a.omega = 1.85f;
+  a.accel_row = L.ny - 2; a.accel_out = accel ? 1 : 0; a.a1 = 0.1f * 0.01f / 9.f; a.a2 = 0.1f * 0.01f / 36.f;
+  a.partials1 = L.partials[q]; a.partials2 = L.partials[q] + (long)L.nx * L.ny / 512;
+  a.prev1 = a.prev2 = nullptr;
+  const int grid = (L.nx / TX) * (L.ny / TY);
+  hipLaunchKernelGGL((lbm::lbm_sweep2<TX, TY, MODE>), dim3(grid), dim3(lbm::kBlock), 0, st, a);
+}
+
+// state after `pairs` x 2 steps with the two-step kernel vs 2 x pairs single steps: must agree
+template <int TX, int TY, int MODE>
+static void selfcheck(Lat& L, hipStream_t st, int pairs) {
+  const size_t nb = sizeof(float) * 9 * L.plane;
+  std::vector<float> init(9 * L.plane), r1(9 * L.plane), r2(9 * L.plane);
+  CK(hipMemcpy(init.data(), L.lat[0], nb, hipMemcpyDeviceToHost));
+  int cur = 0;
+  // the accelerate phase of the first step, as lbm_run's prologue does it
+  hipLaunchKernelGGL(lbm::lbm_accelerate_row, dim3((L.nx + 255) / 256), dim3(256), 0, st, L.lat[0], L.plane, L.pitch,
+                     L.nx, L.ny - 2, L.blocked, 0.1f * 0.01f / 9.f, 0.1f * 0.01f / 36.f);
+  for (int t = 0; t < 2 * pairs; ++t) { launch<4, MODE>(L, cur, t & 1, st, t != 2 * pairs - 1); cur ^= 1; }
+  CK(hipStreamSynchronize(st));
+  CK(hipMemcpy(r1.data(), L.lat[cur], nb, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(L.lat[0], init.data(), nb, hipMemcpyHostToDevice));
+  cur = 0;
+  hipLaunchKernelGGL(lbm::lbm_accelerate_row, dim3((L.nx + 255) / 256), dim3(256), 0, st, L.lat[0], L.plane, L.pitch,
+                     L.nx, L.ny - 2, L.blocked, 0.1f * 0.01f / 9.f, 0.1f * 0.01f / 36.f);
+  for (int t = 0; t < pairs; ++t) { launch2<TX, TY, MODE>(L, cur, t & 1, st, t != pairs - 1); cur ^= 1; }
+  CK(hipStreamSynchronize(st));
+  CK(hipMemcpy(r2.data(), L.lat[cur], nb, hipMemcpyDeviceToHost));
+  double maxd = 0, maxv = 0; long ndiff = 0;
+  for (int k = 0; k < 9; ++k)
+    for (int y = 0; y < L.ny; ++y)
+      for (int x = 0; x < L.nx; ++x) {
+        const size_t i = (size_t)k * L.plane + (size_t)y * L.pitch + x;
+        const double d = fabs((double)r1[i] - (double)r2[i]);
+        if (d > maxd) maxd = d;
+        if (fabs(r1[i]) > maxv) maxv = fabs(r1[i]);
+        if (r1[i] != r2[i]) ++ndiff;
+      }
+  printf("# selfcheck sweep2<%d,%d,%d> vs 2x sweep<4>: %d pairs, max |diff| %.3e (max |f| %.3e), %ld values differ\n",
+         TX, TY, MODE, pairs, maxd, maxv, ndiff);
+  CK(hipMemcpy(L.lat[0], init.data(), nb, hipMemcpyHostToDevice));
+}
+
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 8192;
   const int steps = argc > 2 ? atoi(argv[2]) : 60;
@@ -75,15 +124,25 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(st));
   }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  struct Var { const char* name; void (*fn)(const Lat&, int, int, hipStream_t, bool); };
+  struct Var { const char* name; void (*fn)(const Lat&, int, int, hipStream_t, bool); int steps_per_launch = 1; };
+  if (n <= 2048) {
+    selfcheck<64, 16, lbm::kFastMath>(L, st, 3);
+    selfcheck<128, 8, lbm::kFastMath>(L, st, 5);
+    selfcheck<32, 32, 0>(L, st, 4);
+  }
   using namespace lbm;
   const Var vars[] = {
       {"copy9", launch_copy9},
       {"V4", launch<4, 0>}, {"V4 fast", launch<4, kFastMath>}, {"V4 fast nts", launch<4, kFastMath | kNtStore>},
-      {"V4 fast ntl", launch<4, kFastMath | kNtLoad>}, {"V4 fast ntl nts", launch<4, kFastMath | kNtLoad | kNtStore>},
+      {"V4 fast ntl nts", launch<4, kFastMath | kNtLoad | kNtStore>},
       {"V2", launch<2, 0>}, {"V2 fast", launch<2, kFastMath>}, {"V2 fast nts", launch<2, kFastMath | kNtStore>},
-      {"V2 fast ntl", launch<2, kFastMath | kNtLoad>}, {"V2 fast ntl nts", launch<2, kFastMath | kNtLoad | kNtStore>},
+      {"V2 fast ntl nts", launch<2, kFastMath | kNtLoad | kNtStore>},
       {"V1 fast", launch<1, kFastMath>},
+      {"T2 64x16 fast", launch2<64, 16, kFastMath>, 2}, {"T2 64x16 fast nt", launch2<64, 16, kFastMath | kNtLoad | kNtStore>, 2},
+      {"T2 64x16 fast nts", launch2<64, 16, kFastMath | kNtStore>, 2},
+      {"T2 128x8 fast", launch2<128, 8, kFastMath>, 2}, {"T2 128x8 fast nt", launch2<128, 8, kFastMath | kNtLoad | kNtStore>, 2},
+      {"T2 32x32 fast", launch2<32, 32, kFastMath>, 2}, {"T2 32x32 fast nt", launch2<32, 32, kFastMath | kNtLoad | kNtStore>, 2},
+      {"T2 256x4 fast", launch2<256, 4, kFastMath>, 2},
       {"V4 nomath", launch<4, kBenchNoMath>}, {"V4 fast aligned", launch<4, kFastMath | kBenchAlignedOnly>},
       {"V4 nomath aligned", launch<4, kBenchNoMath | kBenchAlignedOnly>},
       {"V2 nomath", launch<2, kBenchNoMath>}, {"V2 fast aligned", launch<2, kFastMath | kBenchAlignedOnly>},
@@ -98,7 +157,7 @@ int main(int argc, char** argv) {
       CK(hipEventRecord(e1, st));
       CK(hipStreamSynchronize(st));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-      if (r > 0) us[v].push_back(ms * 1e3 / steps);
+      if (r > 0) us[v].push_back(ms * 1e3 / steps / vars[v].steps_per_launch);
     }
   }
   printf("# n=%d steps=%d rounds=%d plane_pad=%ld B\n", n, steps, rounds, pad);
