@@ -78,12 +78,6 @@ __device__ __forceinline__ T block_sum(T v, T* red) {
   return r;
 }
 
-// One cell: p[] holds the nine pulled values on entry and the nine values to
-// store on exit.  Returns the cell's contribution to the step's speed sum.
-// Arithmetic follows SURVEY.md Appendix A (= d2q9-bgk.c:982-1130) with
-// c_sq = 1/3 folded into the constants: 1/c_sq = 3, 1/(2 c_sq^2) = 4.5,
-// 1/(2 c_sq) = 1.5, and one reciprocal of the density shared by both
-// velocity components (the reference's own -Ofast build does the same).
 // Kernel mode bits (template parameter MODE of lbm_sweep).
 constexpr int kFastMath = 1;   // v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of the IEEE sequences
 constexpr int kNtStore = 2;    // nontemporal stores of the destination lattice
@@ -98,8 +92,20 @@ template <bool FAST> __device__ __forceinline__ float root(float x) {
   if constexpr (FAST) return __builtin_amdgcn_sqrtf(x); else return sqrtf(x);
 }
 
+// One cell: p[] holds the nine pulled values on entry and the nine values to
+// store on exit.  Returns the cell's contribution to the step's speed sum.
+// Arithmetic follows SURVEY.md Appendix A (= d2q9-bgk.c:982-1130) with
+// c_sq = 1/3 folded into the constants: 1/c_sq = 3, 1/(2 c_sq^2) = 4.5,
+// 1/(2 c_sq) = 1.5, and one reciprocal of the density shared by both
+// velocity components (the reference's own -Ofast build does the same).
+// Every multiply-add below is spelled out (fmaf) and contraction is switched off for the
+// function, so the sequence of float operations per cell is fixed by this text and not by
+// what the optimiser happens to fuse in a given instantiation: all kernels built from it
+// (1, 2 or 4 cells per thread, one or two steps per pass, any slab decomposition) produce
+// bit-identical lattices.
 template <bool FAST>
 __device__ __forceinline__ float collide_cell(float (&p)[9], bool is_blocked, float omega) {
+#pragma clang fp contract(off)
   const float w0 = 4.f / 9.f, w1 = 1.f / 9.f, w2 = 1.f / 36.f;
   float rho = p[0];
   rho += p[1]; rho += p[2]; rho += p[3]; rho += p[4];
@@ -107,23 +113,24 @@ __device__ __forceinline__ float collide_cell(float (&p)[9], bool is_blocked, fl
   const float inv = recip<FAST>(rho);
   const float ux = (p[1] + p[5] + p[8] - (p[3] + p[6] + p[7])) * inv;
   const float uy = (p[2] + p[5] + p[6] - (p[4] + p[7] + p[8])) * inv;
-  const float usq = ux * ux + uy * uy;
-  const float base = 1.f - 1.5f * usq;
-  const float r1 = w1 * rho, r2 = w2 * rho;
+  const float usq = __builtin_fmaf(ux, ux, uy * uy);
+  const float base = __builtin_fmaf(-1.5f, usq, 1.f);          // 1 - u_sq / (2 c_sq)
+  const float r0 = w0 * rho, r1 = w1 * rho, r2 = w2 * rho;
   const float upp = ux + uy, upm = ux - uy;
+  // d_k = w_k rho (1 + u_k/c_sq + u_k^2/(2 c_sq^2) - u_sq/(2 c_sq)) = w_k rho (base + u_k (3 + 4.5 u_k))
   float d[9];
-  d[0] = w0 * rho * base;
-  d[1] = r1 * (base + ux * (3.f + 4.5f * ux));
-  d[2] = r1 * (base + uy * (3.f + 4.5f * uy));
-  d[3] = r1 * (base - ux * (3.f - 4.5f * ux));
-  d[4] = r1 * (base - uy * (3.f - 4.5f * uy));
-  d[5] = r2 * (base + upp * (3.f + 4.5f * upp));
-  d[6] = r2 * (base - upm * (3.f - 4.5f * upm));
-  d[7] = r2 * (base - upp * (3.f - 4.5f * upp));
-  d[8] = r2 * (base + upm * (3.f + 4.5f * upm));
+  d[0] = r0 * base;
+  d[1] = r1 * __builtin_fmaf(ux, __builtin_fmaf(4.5f, ux, 3.f), base);
+  d[2] = r1 * __builtin_fmaf(uy, __builtin_fmaf(4.5f, uy, 3.f), base);
+  d[3] = r1 * __builtin_fmaf(-ux, __builtin_fmaf(-4.5f, ux, 3.f), base);
+  d[4] = r1 * __builtin_fmaf(-uy, __builtin_fmaf(-4.5f, uy, 3.f), base);
+  d[5] = r2 * __builtin_fmaf(upp, __builtin_fmaf(4.5f, upp, 3.f), base);
+  d[6] = r2 * __builtin_fmaf(-upm, __builtin_fmaf(-4.5f, upm, 3.f), base);
+  d[7] = r2 * __builtin_fmaf(-upp, __builtin_fmaf(-4.5f, upp, 3.f), base);
+  d[8] = r2 * __builtin_fmaf(upm, __builtin_fmaf(4.5f, upm, 3.f), base);
   float t[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) t[k] = p[k] + omega * (d[k] - p[k]);
+  for (int k = 0; k < 9; ++k) t[k] = __builtin_fmaf(omega, d[k] - p[k], p[k]);   // p + omega (d - p)
   // post-collision speed from the values about to be stored
   float rho2 = t[0];
 #pragma unroll
@@ -131,7 +138,7 @@ __device__ __forceinline__ float collide_cell(float (&p)[9], bool is_blocked, fl
   const float inv2 = recip<FAST>(rho2);
   const float vx = (t[1] + t[5] + t[8] - (t[3] + t[6] + t[7])) * inv2;
   const float vy = (t[2] + t[5] + t[6] - (t[4] + t[7] + t[8])) * inv2;
-  const float speed = root<FAST>(vx * vx + vy * vy);
+  const float speed = root<FAST>(__builtin_fmaf(vx, vx, vy * vy));
   // blocked cell: mirrored pulled values instead, no contribution
   const float b1 = p[3], b2 = p[4], b3 = p[1], b4 = p[2], b5 = p[7], b6 = p[8], b7 = p[5], b8 = p[6];
   p[0] = is_blocked ? p[0] : t[0];
@@ -148,6 +155,7 @@ __device__ __forceinline__ float collide_cell(float (&p)[9], bool is_blocked, fl
 
 // The accelerate phase for one cell of row ny-2 (d2q9-bgk.c:246-258).
 __device__ __forceinline__ void accelerate_cell(float (&p)[9], bool is_blocked, float a1, float a2) {
+#pragma clang fp contract(off)
   if (!is_blocked && (p[3] - a1) > 0.f && (p[6] - a2) > 0.f && (p[7] - a2) > 0.f) {
     p[1] += a1; p[5] += a2; p[8] += a2;
     p[3] -= a1; p[6] -= a2; p[7] -= a2;
