@@ -333,6 +333,13 @@ def write_values(params: Param, state4: np.ndarray, obstacles: np.ndarray, av_ve
 # the slab to the north through 2,5,6 -- three planes of one row per direction, 3*nx floats.
 HALO_PLANES_TO_SOUTH = (4, 7, 8)   # of the sender's row 0
 HALO_PLANES_TO_NORTH = (2, 5, 6)   # of the sender's last row
+# Two steps per pass (lbm_sweep2) trade halos once per PAIR of steps: the adjacent row's cells are
+# recomputed as the tile ring, which takes its centre planes 0,1,3, the three planes that stream
+# across the boundary, and those three planes of the row behind it -- nine rows of nx floats
+# (lbm_kernels.hip.h, kHaloSlots): (row offset from the sender's edge row, plane) per slot.
+HALO9_TO_SOUTH = ((0, 0), (0, 1), (0, 3), (0, 4), (0, 7), (0, 8), (1, 4), (1, 7), (1, 8))
+HALO9_TO_NORTH = ((0, 0), (0, 1), (0, 3), (0, 2), (0, 5), (0, 6), (1, 2), (1, 5), (1, 6))
+TWO_STEP_TILE = (64, 16)           # lattice must tile: nx % 64 == 0, rows per slab % 16 == 0
 
 
 def slab_bounds(ny: int, nslabs: int, slab: int):

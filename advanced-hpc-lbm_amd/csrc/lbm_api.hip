@@ -109,6 +109,8 @@ struct Slab {
   long plane = 0;              // floats per plane
   float* lat[2] = {nullptr, nullptr};
   uint8_t* blocked = nullptr;
+  uint8_t* blocked_gs = nullptr;   // blocked map of the row below the slab (global row0-1) ...
+  uint8_t* blocked_gn = nullptr;   // ... and of the row above it (two-step kernel ring rows)
   float* ghost_s[2] = {nullptr, nullptr};  // halo received from the south neighbour: planes 2,5,6
   float* ghost_n[2] = {nullptr, nullptr};  // halo received from the north neighbour: planes 4,7,8
   float* send_s[2] = {nullptr, nullptr};   // own row 0, planes 4,7,8 (goes south)
@@ -174,7 +176,9 @@ int slab_alloc(lbm_ctx* c, Slab& s, bool exchanging) {
   s.scratch_cap = s.partial_cap;
   HIPC(hipMalloc((void**)&s.scratch_d, sizeof(double) * (s.scratch_cap + 8)));
   if (exchanging) {
-    const size_t hb = sizeof(float) * 3 * (size_t)nx;
+    const size_t hb = sizeof(float) * lbm::kHaloSlots * (size_t)nx;
+    HIPC(hipMalloc((void**)&s.blocked_gs, (size_t)nx));
+    HIPC(hipMalloc((void**)&s.blocked_gn, (size_t)nx));
     for (int i = 0; i < 2; ++i) {
       HIPC(hipMalloc((void**)&s.ghost_s[i], hb));
       HIPC(hipMalloc((void**)&s.ghost_n[i], hb));
@@ -208,6 +212,15 @@ int slab_upload(lbm_ctx* c, Slab& s, const int* obstacles, const float* cells) {
     HIPC(hipMemcpyAsync(d_ob, obstacles + (long)s.row0 * nx, sizeof(int) * ncell, hipMemcpyHostToDevice, s.sc));
     hipLaunchKernelGGL(lbm::lbm_pack_blocked, dim3(grid), dim3(256), 0, s.sc, d_ob, s.blocked, s.pitch, nx, ncell);
     HIPC(hipGetLastError());
+    if (s.blocked_gs) {  // rows just outside the slab (periodic in the global lattice)
+      const int ny = c->p.ny;
+      const int rs = (s.row0 + ny - 1) % ny, rn = (s.row0 + s.nyl) % ny;
+      std::vector<uint8_t> gs(nx), gn(nx);
+      for (int x = 0; x < nx; ++x) { gs[x] = obstacles[(long)rs * nx + x] ? 1 : 0; gn[x] = obstacles[(long)rn * nx + x] ? 1 : 0; }
+      HIPC(hipMemcpyAsync(s.blocked_gs, gs.data(), nx, hipMemcpyHostToDevice, s.sc));
+      HIPC(hipMemcpyAsync(s.blocked_gn, gn.data(), nx, hipMemcpyHostToDevice, s.sc));
+      HIPC(hipStreamSynchronize(s.sc));
+    }
     HIPC(hipStreamSynchronize(s.sc));
     HIPC(hipFree(d_ob));
   }
@@ -259,23 +272,32 @@ void pick_defaults(lbm_ctx* c) {
   if ((e = getenv("LBM_TIME_BLOCK"))) c->time_block = atoi(e) == 2 ? 2 : 1;
 }
 
-// The two-step kernel covers whole tiles of one periodic slab.
+// The two-step kernel covers whole 64 x 16 tiles.  With neighbours every slab must tile too,
+// and every rank must come to the same answer (the halo message size depends on it).
 bool t2_eligible(const lbm_ctx* c) {
-  return c->time_block == 2 && c->exchange == 0 && c->slabs.size() == 1 && c->p.nx % kT2X == 0 &&
-         c->p.ny % kT2Y == 0;
+  if (c->time_block != 2 || c->p.nx % kT2X != 0) return false;
+  if (c->exchange == 0) return c->slabs.size() == 1 && c->p.ny % kT2Y == 0;
+  return c->p.ny % (c->nranks * kT2Y) == 0;
 }
 
-template <int MODE>
-void launch_sweep2_m(const lbm::Sweep2Args& a, int grid, hipStream_t st) {
-  hipLaunchKernelGGL((lbm::lbm_sweep2<kT2X, kT2Y, MODE>), dim3(grid), dim3(lbm::kBlock), 0, st, a);
+template <int MODE, bool EDGE>
+void launch_sweep2_me(const lbm::Sweep2Args& a, int grid, hipStream_t st) {
+  hipLaunchKernelGGL((lbm::lbm_sweep2<kT2X, kT2Y, MODE, EDGE>), dim3(grid), dim3(lbm::kBlock), 0, st, a);
 }
 
-void launch_sweep2(const lbm_ctx* c, const lbm::Sweep2Args& a, int grid, hipStream_t st) {
+void launch_sweep2(const lbm_ctx* c, const lbm::Sweep2Args& a, int grid, hipStream_t st, bool edge) {
   // cache-resident lattices: default policy; streamed lattices: nontemporal stores (kbench)
-  const bool nts = (c->variant & lbm::kNtStore) != 0;
-  const bool fast = (c->variant & lbm::kFastMath) != 0;
-  if (fast) { if (nts) launch_sweep2_m<lbm::kFastMath | lbm::kNtStore>(a, grid, st); else launch_sweep2_m<lbm::kFastMath>(a, grid, st); }
-  else { if (nts) launch_sweep2_m<lbm::kNtStore>(a, grid, st); else launch_sweep2_m<0>(a, grid, st); }
+  const int mode = (int)(c->variant & (lbm::kFastMath | lbm::kNtStore));
+  switch (mode * 2 + (edge ? 1 : 0)) {
+    case 0: launch_sweep2_me<0, false>(a, grid, st); break;
+    case 1: launch_sweep2_me<0, true>(a, grid, st); break;
+    case 2: launch_sweep2_me<1, false>(a, grid, st); break;
+    case 3: launch_sweep2_me<1, true>(a, grid, st); break;
+    case 4: launch_sweep2_me<2, false>(a, grid, st); break;
+    case 5: launch_sweep2_me<2, true>(a, grid, st); break;
+    case 6: launch_sweep2_me<3, false>(a, grid, st); break;
+    default: launch_sweep2_me<3, true>(a, grid, st); break;
+  }
 }
 
 void slab_free(Slab& s) {
@@ -291,6 +313,8 @@ void slab_free(Slab& s) {
     if (s.ev_recv[i]) (void)hipEventDestroy(s.ev_recv[i]);
   }
   if (s.blocked) (void)hipFree(s.blocked);
+  if (s.blocked_gs) (void)hipFree(s.blocked_gs);
+  if (s.blocked_gn) (void)hipFree(s.blocked_gn);
   if (s.sums) (void)hipFree(s.sums);
   if (s.scratch_d) (void)hipFree(s.scratch_d);
   if (s.ev_t0) (void)hipEventDestroy(s.ev_t0);
@@ -348,9 +372,11 @@ void launch_sweep(const lbm_ctx* c, const lbm::SweepArgs& a, hipStream_t st) {
   }
 }
 
-// Halo exchange for parity q on the exchange streams (all local slabs).
-int exchange_halos(lbm_ctx* c, int q) {
-  const size_t n = 3 * (size_t)c->p.nx;
+// Halo exchange for parity q on the exchange streams (all local slabs): slots
+// [slot0, slot0 + nslots) of the nine-slot halo buffers (lbm_kernels.hip.h, kHaloSlots).
+int exchange_halos(lbm_ctx* c, int q, int slot0, int nslots) {
+  const size_t off = (size_t)slot0 * c->p.nx;
+  const size_t n = (size_t)nslots * c->p.nx;
   const int ns = (int)c->slabs.size();
   if (c->exchange == LBM_EXCHANGE_RCCL) {
     for (auto& s : c->slabs) {
@@ -363,10 +389,10 @@ int exchange_halos(lbm_ctx* c, int q) {
       const int me = c->rank_mode ? c->rank : i;
       const int south = (me + c->nranks - 1) % c->nranks, north = (me + 1) % c->nranks;
       // order matters when south == north (2 ranks): sends S then N, receives N then S
-      NCCLC(rccl::Send(s.send_s[q], n, rccl::kFloat32, south, s.comm, s.sx));
-      NCCLC(rccl::Send(s.send_n[q], n, rccl::kFloat32, north, s.comm, s.sx));
-      NCCLC(rccl::Recv(s.ghost_n[q], n, rccl::kFloat32, north, s.comm, s.sx));
-      NCCLC(rccl::Recv(s.ghost_s[q], n, rccl::kFloat32, south, s.comm, s.sx));
+      NCCLC(rccl::Send(s.send_s[q] + off, n, rccl::kFloat32, south, s.comm, s.sx));
+      NCCLC(rccl::Send(s.send_n[q] + off, n, rccl::kFloat32, north, s.comm, s.sx));
+      NCCLC(rccl::Recv(s.ghost_n[q] + off, n, rccl::kFloat32, north, s.comm, s.sx));
+      NCCLC(rccl::Recv(s.ghost_s[q] + off, n, rccl::kFloat32, south, s.comm, s.sx));
     }
     NCCLC(rccl::GroupEnd());
     for (auto& s : c->slabs) {
@@ -382,8 +408,8 @@ int exchange_halos(lbm_ctx* c, int q) {
       HIPC(hipStreamWaitEvent(s.sx, s.ev_bnd[q], 0));
       HIPC(hipStreamWaitEvent(s.sx, so.ev_bnd[q], 0));
       HIPC(hipStreamWaitEvent(s.sx, no.ev_bnd[q], 0));
-      HIPC(hipMemcpyAsync(s.ghost_s[q], so.send_n[q], sizeof(float) * n, hipMemcpyDeviceToDevice, s.sx));
-      HIPC(hipMemcpyAsync(s.ghost_n[q], no.send_s[q], sizeof(float) * n, hipMemcpyDeviceToDevice, s.sx));
+      HIPC(hipMemcpyAsync(s.ghost_s[q] + off, so.send_n[q] + off, sizeof(float) * n, hipMemcpyDeviceToDevice, s.sx));
+      HIPC(hipMemcpyAsync(s.ghost_n[q] + off, no.send_s[q] + off, sizeof(float) * n, hipMemcpyDeviceToDevice, s.sx));
       HIPC(hipEventRecord(s.ev_recv[q], s.sx));
     }
   }
@@ -542,76 +568,58 @@ extern "C" int lbm_slab_rows(const lbm_ctx* ctx, int slab, int* row_begin, int* 
   return LBM_OK;
 }
 
-extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
-  if (!c) return fail(LBM_EINVAL, "ctx is NULL");
-  if (nsteps < 0) return fail(LBM_EINVAL, "nsteps < 0");
-  if (nsteps == 0) { c->gpu_ms = c->wall_ms = 0.0; return LBM_OK; }
+namespace {
+
+// One single-step launch group (all local slabs) for step tt, launch index li.
+int launch_single(lbm_ctx* c, int li, int tt, bool last, bool fold_prev, float a1, float a2) {
   const int nx = c->p.nx;
-  const float a1 = c->p.density * c->p.accel / 9.f;   // d2q9-bgk.c:230-231
-  const float a2 = c->p.density * c->p.accel / 36.f;
+  const int q = li & 1, qp = q ^ 1;
   const bool ex = c->exchange != 0;
+  const long h3 = 3L * nx;  // one-step halos live in slots 3..5 of the nine-slot buffers
   int rc;
-
-  for (auto& s : c->slabs)
-    if ((rc = ensure_sums(s, nsteps))) return rc;
-
-  // ---- prologue: accelerate phase of the first step; first halo exchange
   for (auto& s : c->slabs) {
     HIPC(hipSetDevice(s.dev));
-    if (s.accel_row >= 0) {
-      hipLaunchKernelGGL(lbm::lbm_accelerate_row, dim3(cdiv(nx, 256)), dim3(256), 0, s.sc,
-                         s.lat[c->cur], s.plane, s.pitch, nx, s.accel_row, s.blocked, a1, a2);
+    lbm::SweepArgs a;
+    a.src = s.lat[c->cur];
+    a.dst = s.lat[c->cur ^ 1];
+    a.plane = s.plane; a.pitch = s.pitch; a.nx = nx; a.nyl = s.nyl;
+    a.blocked = s.blocked;
+    a.omega = c->p.omega;
+    a.accel_row = last ? -1 : s.accel_row;
+    a.a1 = a1; a.a2 = a2;
+    a.partials = s.partials[q];
+    a.prev_partials = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
+    if (!ex) {
+      // one slab, periodic self-wrap: the halo rows are the slab's own edge rows
+      const long top = (long)(s.nyl - 1) * s.pitch;
+      a.south2 = a.src + 2 * s.plane + top; a.south5 = a.src + 5 * s.plane + top; a.south6 = a.src + 6 * s.plane + top;
+      a.north4 = a.src + 4 * s.plane; a.north7 = a.src + 7 * s.plane; a.north8 = a.src + 8 * s.plane;
+      a.send_south = a.send_north = nullptr;
+      a.y_begin = 0; a.y_count = s.nyl; a.y_stride = 1;
+      const int nb = sweep_blocks(c, a.y_count);
+      if (fold_prev) { a.prev_partials = s.partials[qp]; a.prev_count = nb; a.prev_sum = s.sums + (tt - 1); }
+      launch_sweep(c, a, s.sc);
       HIPC(hipGetLastError());
-    }
-    if (ex) {
-      hipLaunchKernelGGL(lbm::lbm_pack_halos, dim3(cdiv(nx, 256)), dim3(256), 0, s.sc,
-                         s.lat[c->cur], s.plane, s.pitch, nx, s.nyl, s.send_s[1], s.send_n[1]);
+    } else {
+      a.south2 = s.ghost_s[qp] + h3; a.south5 = s.ghost_s[qp] + h3 + nx; a.south6 = s.ghost_s[qp] + h3 + 2 * nx;
+      a.north4 = s.ghost_n[qp] + h3; a.north7 = s.ghost_n[qp] + h3 + nx; a.north8 = s.ghost_n[qp] + h3 + 2 * nx;
+      a.send_south = s.send_s[q] + h3; a.send_north = s.send_n[q] + h3;
+      // boundary rows first: they feed the exchange
+      const int nb_rows = s.nyl >= 2 ? 2 : 1;
+      a.y_begin = 0; a.y_count = nb_rows; a.y_stride = s.nyl >= 2 ? s.nyl - 1 : 1;
+      const int nbb = sweep_blocks(c, nb_rows);
+      const int nbi = s.nyl > 2 ? sweep_blocks(c, s.nyl - 2) : 0;
+      if (fold_prev) { a.prev_partials = s.partials[qp]; a.prev_count = nbb + nbi; a.prev_sum = s.sums + (tt - 1); }
+      HIPC(hipStreamWaitEvent(s.sc, s.ev_recv[qp], 0));
+      launch_sweep(c, a, s.sc);
       HIPC(hipGetLastError());
-      HIPC(hipEventRecord(s.ev_bnd[1], s.sc));
+      HIPC(hipEventRecord(s.ev_bnd[q], s.sc));
     }
   }
-  if (ex && (rc = exchange_halos(c, 1))) return rc;
-
-  const auto wall0 = std::chrono::steady_clock::now();
-  for (auto& s : c->slabs) {
-    HIPC(hipSetDevice(s.dev));
-    HIPC(hipEventRecord(s.ev_t0, s.sc));
-  }
-
-  // ---- the step loop (reference d2q9-bgk.c:180-201); no host sync inside
-  int tt0 = 0;
-  if (t2_eligible(c) && nsteps >= 2) {
-    // pairs of steps fused through LDS; a trailing odd step takes the single-step path below
-    Slab& s = c->slabs[0];
-    HIPC(hipSetDevice(s.dev));
-    const int npairs = nsteps / 2;
-    const int nblk = (nx / kT2X) * (c->p.ny / kT2Y);
-    for (int j = 0; j < npairs; ++j) {
-      const int q = j & 1;
-      lbm::Sweep2Args a;
-      a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
-      a.plane = s.plane; a.pitch = s.pitch; a.nx = nx; a.ny = s.nyl;
-      a.blocked = s.blocked; a.omega = c->p.omega;
-      a.accel_row = s.accel_row;
-      a.accel_out = (2 * j + 2 < nsteps) ? 1 : 0;
-      a.a1 = a1; a.a2 = a2;
-      a.partials1 = s.partials[q]; a.partials2 = s.partials[q] + nblk;
-      a.prev1 = a.prev2 = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
-      if (j > 0) { a.prev1 = s.partials[q ^ 1]; a.prev2 = s.partials[q ^ 1] + nblk; a.prev_count = nblk; a.prev_sum = s.sums + 2 * (j - 1); }
-      launch_sweep2(c, a, nblk, s.sc);
-      HIPC(hipGetLastError());
-      c->cur ^= 1;
-    }
-    const int ql2 = (npairs - 1) & 1;
-    hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql2], nblk, s.sums + 2 * (npairs - 1));
-    hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql2] + nblk, nblk, s.sums + 2 * (npairs - 1) + 1);
-    HIPC(hipGetLastError());
-    tt0 = 2 * npairs;
-  }
-  for (int tt = tt0; tt < nsteps; ++tt) {
-    const int q = tt & 1, qp = q ^ 1;
-    const bool last = (tt == nsteps - 1);
+  if (ex) {
+    if ((rc = exchange_halos(c, q, 3, 3))) return rc;
     for (auto& s : c->slabs) {
+      if (s.nyl <= 2) continue;
       HIPC(hipSetDevice(s.dev));
       lbm::SweepArgs a;
       a.src = s.lat[c->cur];
@@ -621,69 +629,155 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
       a.omega = c->p.omega;
       a.accel_row = last ? -1 : s.accel_row;
       a.a1 = a1; a.a2 = a2;
-      a.partials = s.partials[q];
+      a.south2 = a.south5 = a.south6 = a.north4 = a.north7 = a.north8 = nullptr;  // interior rows never touch halos
+      a.send_south = a.send_north = nullptr;
+      a.y_begin = 1; a.y_count = s.nyl - 2; a.y_stride = 1;
+      a.partials = s.partials[q] + sweep_blocks(c, 2);
       a.prev_partials = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
-      if (!ex) {
-        // one slab, periodic self-wrap: the halo rows are the slab's own edge rows
-        const long top = (long)(s.nyl - 1) * s.pitch;
-        a.south2 = a.src + 2 * s.plane + top; a.south5 = a.src + 5 * s.plane + top; a.south6 = a.src + 6 * s.plane + top;
-        a.north4 = a.src + 4 * s.plane; a.north7 = a.src + 7 * s.plane; a.north8 = a.src + 8 * s.plane;
-        a.send_south = a.send_north = nullptr;
-        a.y_begin = 0; a.y_count = s.nyl; a.y_stride = 1;
-        const int nb = sweep_blocks(c, a.y_count);
-        if (tt > tt0) { a.prev_partials = s.partials[qp]; a.prev_count = nb; a.prev_sum = s.sums + (tt - 1); }
-        launch_sweep(c, a, s.sc);
-        HIPC(hipGetLastError());
-      } else {
-        a.south2 = s.ghost_s[qp]; a.south5 = s.ghost_s[qp] + nx; a.south6 = s.ghost_s[qp] + 2 * nx;
-        a.north4 = s.ghost_n[qp]; a.north7 = s.ghost_n[qp] + nx; a.north8 = s.ghost_n[qp] + 2 * nx;
-        a.send_south = s.send_s[q]; a.send_north = s.send_n[q];
-        // boundary rows first: they feed the exchange
-        const int nb_rows = s.nyl >= 2 ? 2 : 1;
-        a.y_begin = 0; a.y_count = nb_rows; a.y_stride = s.nyl >= 2 ? s.nyl - 1 : 1;
-        const int nbb = sweep_blocks(c, nb_rows);
-        const int nbi = s.nyl > 2 ? sweep_blocks(c, s.nyl - 2) : 0;
-        if (tt > tt0) { a.prev_partials = s.partials[qp]; a.prev_count = nbb + nbi; a.prev_sum = s.sums + (tt - 1); }
-        HIPC(hipStreamWaitEvent(s.sc, s.ev_recv[qp], 0));
-        launch_sweep(c, a, s.sc);
-        HIPC(hipGetLastError());
-        HIPC(hipEventRecord(s.ev_bnd[q], s.sc));
-      }
+      launch_sweep(c, a, s.sc);
+      HIPC(hipGetLastError());
     }
-    if (ex) {
-      if ((rc = exchange_halos(c, q))) return rc;
-      for (auto& s : c->slabs) {
-        if (s.nyl <= 2) continue;
-        HIPC(hipSetDevice(s.dev));
-        lbm::SweepArgs a;
-        a.src = s.lat[c->cur];
-        a.dst = s.lat[c->cur ^ 1];
-        a.plane = s.plane; a.pitch = s.pitch; a.nx = nx; a.nyl = s.nyl;
-        a.blocked = s.blocked;
-        a.omega = c->p.omega;
-        a.accel_row = last ? -1 : s.accel_row;
-        a.a1 = a1; a.a2 = a2;
-        a.south2 = a.south5 = a.south6 = a.north4 = a.north7 = a.north8 = nullptr;  // interior rows never touch halos
-        a.send_south = a.send_north = nullptr;
-        a.y_begin = 1; a.y_count = s.nyl - 2; a.y_stride = 1;
-        a.partials = s.partials[q] + sweep_blocks(c, 2);
-        a.prev_partials = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
-        launch_sweep(c, a, s.sc);
-        HIPC(hipGetLastError());
-      }
-    }
-    c->cur ^= 1;
   }
+  c->cur ^= 1;
+  return LBM_OK;
+}
 
-  // ---- epilogue: fold the last step's partials, collect the per-step sums
-  const int ql = (nsteps - 1) & 1;
+int single_partial_count(const lbm_ctx* c, const Slab& s) {
+  if (c->exchange == 0) return sweep_blocks(c, s.nyl);
+  return sweep_blocks(c, s.nyl >= 2 ? 2 : 1) + (s.nyl > 2 ? sweep_blocks(c, s.nyl - 2) : 0);
+}
+
+// One two-step launch group (all local slabs) for steps tt, tt+1, launch index li.
+int launch_pair(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev, float a1, float a2) {
+  const int nx = c->p.nx;
+  const int q = li & 1, qp = q ^ 1;
+  const bool ex = c->exchange != 0;
+  const int ntx = nx / kT2X;
+  int rc;
+  auto fill = [&](Slab& s, lbm::Sweep2Args& a) {
+    const int nbtot = ntx * (s.nyl / kT2Y);
+    a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
+    a.plane = s.plane; a.pitch = s.pitch; a.nx = nx; a.ny = s.nyl;
+    a.blocked = s.blocked; a.omega = c->p.omega;
+    a.accel_row = s.accel_row >= 0 ? s.accel_row : lbm::kNoRow;
+    a.accel_out = accel_out ? 1 : 0;
+    a.a1 = a1; a.a2 = a2;
+    a.partials1 = s.partials[q]; a.partials2 = s.partials[q] + nbtot;
+    a.prev1 = a.prev2 = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
+    a.ghost_s = a.ghost_n = nullptr; a.blocked_gs = a.blocked_gn = nullptr; a.send_s = a.send_n = nullptr;
+    return nbtot;
+  };
   for (auto& s : c->slabs) {
     HIPC(hipSetDevice(s.dev));
-    if (tt0 < nsteps) {  // the last step ran on the single-step path: fold its partials
-      int count;
-      if (!ex) count = sweep_blocks(c, s.nyl);
-      else count = sweep_blocks(c, s.nyl >= 2 ? 2 : 1) + (s.nyl > 2 ? sweep_blocks(c, s.nyl - 2) : 0);
-      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql], count, s.sums + (nsteps - 1));
+    lbm::Sweep2Args a;
+    const int nbtot = fill(s, a);
+    const int nty = s.nyl / kT2Y;
+    if (fold_prev) { a.prev1 = s.partials[qp]; a.prev2 = s.partials[qp] + nbtot; a.prev_count = nbtot; a.prev_sum = s.sums + (tt - 2); }
+    if (!ex) {
+      a.by_begin = 0; a.by_count = nty; a.by_stride = 1;
+      launch_sweep2(c, a, nbtot, s.sc, false);
+      HIPC(hipGetLastError());
+    } else {
+      // edge tile rows first: they consume the halos of the previous pair and pack the next ones
+      a.by_begin = 0; a.by_count = nty >= 2 ? 2 : 1; a.by_stride = nty >= 2 ? nty - 1 : 1;
+      a.ghost_s = s.ghost_s[qp]; a.ghost_n = s.ghost_n[qp];
+      a.blocked_gs = s.blocked_gs; a.blocked_gn = s.blocked_gn;
+      a.send_s = s.send_s[q]; a.send_n = s.send_n[q];
+      HIPC(hipStreamWaitEvent(s.sc, s.ev_recv[qp], 0));
+      launch_sweep2(c, a, ntx * a.by_count, s.sc, true);
+      HIPC(hipGetLastError());
+      HIPC(hipEventRecord(s.ev_bnd[q], s.sc));
+    }
+  }
+  if (ex) {
+    if ((rc = exchange_halos(c, q, 0, lbm::kHaloSlots))) return rc;
+    for (auto& s : c->slabs) {
+      const int nty = s.nyl / kT2Y;
+      if (nty <= 2) continue;
+      HIPC(hipSetDevice(s.dev));
+      lbm::Sweep2Args a;
+      fill(s, a);
+      a.by_begin = 1; a.by_count = nty - 2; a.by_stride = 1;
+      a.partials1 += 2 * ntx; a.partials2 += 2 * ntx;   // after the two edge tile rows
+      launch_sweep2(c, a, ntx * (nty - 2), s.sc, false);
+      HIPC(hipGetLastError());
+    }
+  }
+  c->cur ^= 1;
+  return LBM_OK;
+}
+
+}  // namespace
+
+extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
+  if (!c) return fail(LBM_EINVAL, "ctx is NULL");
+  if (nsteps < 0) return fail(LBM_EINVAL, "nsteps < 0");
+  if (nsteps == 0) { c->gpu_ms = c->wall_ms = 0.0; return LBM_OK; }
+  const int nx = c->p.nx;
+  const float a1 = c->p.density * c->p.accel / 9.f;   // d2q9-bgk.c:230-231
+  const float a2 = c->p.density * c->p.accel / 36.f;
+  const bool ex = c->exchange != 0;
+  const bool pairs = t2_eligible(c) && nsteps >= 2;
+  int rc;
+
+  for (auto& s : c->slabs)
+    if ((rc = ensure_sums(s, nsteps))) return rc;
+
+  // ---- prologue: accelerate phase of the first step; first halo exchange (parity 1 = "launch -1")
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    if (s.accel_row >= 0) {
+      hipLaunchKernelGGL(lbm::lbm_accelerate_row, dim3(cdiv(nx, 256)), dim3(256), 0, s.sc,
+                         s.lat[c->cur], s.plane, s.pitch, nx, s.accel_row, s.blocked, a1, a2);
+      HIPC(hipGetLastError());
+    }
+    if (ex) {
+      if (s.nyl >= 2)
+        hipLaunchKernelGGL(lbm::lbm_pack_halos9, dim3(cdiv(nx, 256)), dim3(256), 0, s.sc,
+                           s.lat[c->cur], s.plane, s.pitch, nx, s.nyl, s.send_s[1], s.send_n[1]);
+      else
+        hipLaunchKernelGGL(lbm::lbm_pack_halos, dim3(cdiv(nx, 256)), dim3(256), 0, s.sc,
+                           s.lat[c->cur], s.plane, s.pitch, nx, s.nyl, s.send_s[1] + 3L * nx, s.send_n[1] + 3L * nx);
+      HIPC(hipGetLastError());
+      HIPC(hipEventRecord(s.ev_bnd[1], s.sc));
+    }
+  }
+  if (ex && (rc = pairs ? exchange_halos(c, 1, 0, lbm::kHaloSlots) : exchange_halos(c, 1, 3, 3))) return rc;
+
+  const auto wall0 = std::chrono::steady_clock::now();
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    HIPC(hipEventRecord(s.ev_t0, s.sc));
+  }
+
+  // ---- the step loop (reference d2q9-bgk.c:180-201); no host sync inside.
+  // Launch index li numbers the launch groups (a pair of steps or a single step); its parity
+  // selects the halo / partial-sum buffers.
+  int li = 0, tt = 0;
+  if (pairs) {
+    const int npairs = nsteps / 2;
+    for (int j = 0; j < npairs; ++j, ++li, tt += 2)
+      if ((rc = launch_pair(c, li, tt, tt + 2 < nsteps, j > 0, a1, a2))) return rc;
+    const int ql = (li - 1) & 1;
+    for (auto& s : c->slabs) {  // fold the last pair's partials
+      HIPC(hipSetDevice(s.dev));
+      const int nbtot = (nx / kT2X) * (s.nyl / kT2Y);
+      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql], nbtot, s.sums + (tt - 2));
+      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql] + nbtot, nbtot, s.sums + (tt - 1));
+      HIPC(hipGetLastError());
+    }
+  }
+  const int first_single = tt;
+  for (; tt < nsteps; ++tt, ++li)
+    if ((rc = launch_single(c, li, tt, tt == nsteps - 1, tt > first_single, a1, a2))) return rc;
+
+  // ---- epilogue: fold the last single step's partials, collect the per-step sums
+  const int ql = (li - 1) & 1;
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    if (first_single < nsteps) {
+      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql],
+                         single_partial_count(c, s), s.sums + (nsteps - 1));
       HIPC(hipGetLastError());
     }
     HIPC(hipEventRecord(s.ev_t1, s.sc));

@@ -369,14 +369,29 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep(const SweepArgs a) {
 // of row ny-2 as they go into LDS (ring cells included), that of step t+3 to the
 // outputs unless the run ends there.  Speed sums: step t+1 counts the tile's own
 // cells only (not the ring), step t+2 the tile.
+// Halo buffers of a slab (both the one-step and the two-step path use this layout;
+// the one-step path moves slots 3..5 only).  Nine rows of nx floats:
+//   to/from the SOUTH neighbour:  slots 0..5 = planes 0,1,3,4,7,8 of the sender's row 0
+//                                 slots 6..8 = planes 4,7,8       of the sender's row 1
+//     (arrives as the receiver's rows nyl and nyl+1)
+//   to/from the NORTH neighbour:  slots 0..5 = planes 0,1,3,2,5,6 of the sender's row nyl-1
+//                                 slots 6..8 = planes 2,5,6       of the sender's row nyl-2
+//     (arrives as the receiver's rows -1 and -2)
+// Two fused steps need the centre planes 0,1,3 of the adjacent row (its cells are recomputed
+// as the ring), the three planes that stream across the boundary from it, and those three
+// planes of the row behind it: 9 nx floats per direction per PAIR of steps instead of
+// 2 x 3 nx -- half as many messages.
+constexpr int kHaloSlots = 9;
+constexpr int kNoRow = -100;   // "no accelerate row on this slab"
+
 struct Sweep2Args {
   const float* src;
   float* dst;
   long plane;
-  int pitch, nx, ny;           // one slab, periodic in both axes
+  int pitch, nx, ny;           // ny = rows of this slab (the whole lattice if alone)
   const uint8_t* blocked;
   float omega;
-  int accel_row;               // ny-2
+  int accel_row;               // local row of global row ny-2, or kNoRow
   int accel_out;               // apply the accelerate phase to the outputs (0 on the last pair)
   float a1, a2;
   float* partials1;            // per block: speed sum of step t+1
@@ -385,11 +400,23 @@ struct Sweep2Args {
   const float* prev2;
   int prev_count;
   double* prev_sum;            // prev_sum[0], prev_sum[1]
+  // tile rows covered by this launch: by = by_begin + i*by_stride, i in [0, by_count)
+  int by_begin, by_count, by_stride;
+  // EDGE launches only (slab with neighbours): received halos, blocked map of rows -1 / nyl,
+  // outgoing halos
+  const float* ghost_s; const float* ghost_n;
+  const uint8_t* blocked_gs; const uint8_t* blocked_gn;
+  float* send_s; float* send_n;
 };
 
-template <int TX, int TY, int MODE>
+// EDGE = false: the tile rows covered never look outside rows [0, ny) of this slab, or the slab
+// is alone and wraps periodically in y.  EDGE = true: first / last tile row of a slab with
+// neighbours; rows -2, -1, ny, ny+1 come from the halo buffers and the new edge rows are also
+// packed for the neighbours.
+template <int TX, int TY, int MODE, bool EDGE = false>
 __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
   static_assert((TX / 4) * TY == kBlock, "phase B: one thread per 4 cells of the tile");
+  static_assert(TY >= 2, "rows 0,1 (and ny-2, ny-1) must sit in one tile row");
   constexpr bool FAST = (MODE & kFastMath) != 0;
   constexpr bool NTL = (MODE & kNtLoad) != 0, NTS = (MODE & kNtStore) != 0;
   constexpr int IW = TX + 2, IH = TY + 2;          // step-t+1 region: tile + ring
@@ -416,7 +443,8 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
   const int nblk = gridDim.x;
   int b = blockIdx.x;
   if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);
-  const int by = b / ntx, bx = b - by * ntx;
+  const int byi = b / ntx, bx = b - byi * ntx;
+  const int by = a.by_begin + byi * a.by_stride;
   const int X0 = bx * TX, Y0 = by * TY;
   const long P = a.plane;
   const float* s = a.src;
@@ -432,20 +460,55 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
     cxs[m] = cx; cys[m] = cy;
     if (idx < IW * IH) {
       int gx = X0 - 1 + cx; gx += (gx < 0) ? a.nx : 0; gx -= (gx >= a.nx) ? a.nx : 0;
-      int gy = Y0 - 1 + cy; gy += (gy < 0) ? a.ny : 0; gy -= (gy >= a.ny) ? a.ny : 0;
       const int xw = gx ? gx - 1 : a.nx - 1, xe = (gx + 1 == a.nx) ? 0 : gx + 1;
-      const int ys = gy ? gy - 1 : a.ny - 1, yn = (gy + 1 == a.ny) ? 0 : gy + 1;
-      const long rc = (long)gy * a.pitch, rs = (long)ys * a.pitch, rn = (long)yn * a.pitch;
-      q[m][0] = ldg<NTL>(s + rc + gx);
-      q[m][1] = ldg<NTL>(s + P + rc + xw);
-      q[m][2] = ldg<NTL>(s + 2 * P + rs + gx);
-      q[m][3] = ldg<NTL>(s + 3 * P + rc + xe);
-      q[m][4] = ldg<NTL>(s + 4 * P + rn + gx);
-      q[m][5] = ldg<NTL>(s + 5 * P + rs + xw);
-      q[m][6] = ldg<NTL>(s + 6 * P + rs + xe);
-      q[m][7] = ldg<NTL>(s + 7 * P + rn + xe);
-      q[m][8] = ldg<NTL>(s + 8 * P + rn + xw);
-      blk[m] = a.blocked[rc + gx] != 0;
+      int gy = Y0 - 1 + cy;
+      const float *c0, *c1, *c3, *s2, *s5, *s6, *n4, *n7, *n8;   // row bases of the nine pulls
+      if constexpr (!EDGE) {
+        gy += (gy < 0) ? a.ny : 0; gy -= (gy >= a.ny) ? a.ny : 0;
+        const int ys = gy ? gy - 1 : a.ny - 1, yn = (gy + 1 == a.ny) ? 0 : gy + 1;
+        const long rc = (long)gy * a.pitch, rs = (long)ys * a.pitch, rn = (long)yn * a.pitch;
+        c0 = s + rc; c1 = s + P + rc; c3 = s + 3 * P + rc;
+        s2 = s + 2 * P + rs; s5 = s + 5 * P + rs; s6 = s + 6 * P + rs;
+        n4 = s + 4 * P + rn; n7 = s + 7 * P + rn; n8 = s + 8 * P + rn;
+        blk[m] = a.blocked[rc + gx] != 0;
+      } else {
+        // gy in [-1, ny]; its south row in [-2, ny-1], its north row in [0, ny+1]
+        const int nxl = a.nx;
+        const long rc = (long)gy * a.pitch;
+        if (gy < 0) {            // ring row -1: centre planes from the southern halo
+          c0 = a.ghost_s; c1 = a.ghost_s + nxl; c3 = a.ghost_s + 2 * nxl;
+          blk[m] = a.blocked_gs[gx] != 0;
+        } else if (gy >= a.ny) { // ring row ny
+          c0 = a.ghost_n; c1 = a.ghost_n + nxl; c3 = a.ghost_n + 2 * nxl;
+          blk[m] = a.blocked_gn[gx] != 0;
+        } else {
+          c0 = s + rc; c1 = s + P + rc; c3 = s + 3 * P + rc;
+          blk[m] = a.blocked[rc + gx] != 0;
+        }
+        if (gy <= 0) {           // south row is -2 (gy = -1) or -1 (gy = 0)
+          const float* g = a.ghost_s + (gy < 0 ? 6 : 3) * nxl;
+          s2 = g; s5 = g + nxl; s6 = g + 2 * nxl;
+        } else {
+          const long rs = rc - a.pitch;
+          s2 = s + 2 * P + rs; s5 = s + 5 * P + rs; s6 = s + 6 * P + rs;
+        }
+        if (gy >= a.ny - 1) {    // north row is ny (gy = ny-1) or ny+1 (gy = ny)
+          const float* g = a.ghost_n + (gy >= a.ny ? 6 : 3) * nxl;
+          n4 = g; n7 = g + nxl; n8 = g + 2 * nxl;
+        } else {
+          const long rn = rc + a.pitch;
+          n4 = s + 4 * P + rn; n7 = s + 7 * P + rn; n8 = s + 8 * P + rn;
+        }
+      }
+      q[m][0] = ldg<NTL>(c0 + gx);
+      q[m][1] = ldg<NTL>(c1 + xw);
+      q[m][2] = ldg<NTL>(s2 + gx);
+      q[m][3] = ldg<NTL>(c3 + xe);
+      q[m][4] = ldg<NTL>(n4 + gx);
+      q[m][5] = ldg<NTL>(s5 + xw);
+      q[m][6] = ldg<NTL>(s6 + xe);
+      q[m][7] = ldg<NTL>(n7 + xe);
+      q[m][8] = ldg<NTL>(n8 + xw);
       cys[m] = cy | (gy == a.accel_row ? 0x10000 : 0);
     }
   }
@@ -515,10 +578,41 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
     f4a w; w.x = o[k][0]; w.y = o[k][1]; w.z = o[k][2]; w.w = o[k][3];
     stg<NTS>(reinterpret_cast<f4a*>(d + k * P), w);
   }
+  if constexpr (EDGE) {
+    // pack the new edge rows for the neighbours (layout: kHaloSlots comment above)
+    auto put = [&](float* buf, int slot, int k) {
+      f4a w; w.x = o[k][0]; w.y = o[k][1]; w.z = o[k][2]; w.w = o[k][3];
+      *reinterpret_cast<f4a*>(buf + (long)slot * a.nx + X0 + x) = w;
+    };
+    if (gy == 0) { put(a.send_s, 0, 0); put(a.send_s, 1, 1); put(a.send_s, 2, 3); put(a.send_s, 3, 4); put(a.send_s, 4, 7); put(a.send_s, 5, 8); }
+    if (gy == 1) { put(a.send_s, 6, 4); put(a.send_s, 7, 7); put(a.send_s, 8, 8); }
+    if (gy == a.ny - 1) { put(a.send_n, 0, 0); put(a.send_n, 1, 1); put(a.send_n, 2, 3); put(a.send_n, 3, 2); put(a.send_n, 4, 5); put(a.send_n, 5, 6); }
+    if (gy == a.ny - 2) { put(a.send_n, 6, 2); put(a.send_n, 7, 5); put(a.send_n, 8, 6); }
+  }
 
   const float b1 = block_sum<float>(sum1, red_f);
   const float b2 = block_sum<float>(sum2, red_g);
   if (threadIdx.x == 0) { a.partials1[blockIdx.x] = b1; a.partials2[blockIdx.x] = b2; }
+}
+
+// Packs all nine halo slots of a resident lattice (start of a run).  Needs nyl >= 2.
+__global__ void lbm_pack_halos9(const float* lat, long plane, int pitch, int nx, int nyl,
+                                float* out_s, float* out_n) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= nx) return;
+  const long r0 = x, r1 = (long)pitch + x;
+  const long t1 = (long)(nyl - 1) * pitch + x, t2 = (long)(nyl - 2) * pitch + x;
+  const int ks[6] = {0, 1, 3, 4, 7, 8}, kn[6] = {0, 1, 3, 2, 5, 6};
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    out_s[(long)i * nx + x] = lat[ks[i] * plane + r0];
+    out_n[(long)i * nx + x] = lat[kn[i] * plane + t1];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    out_s[(long)(6 + i) * nx + x] = lat[ks[3 + i] * plane + r1];
+    out_n[(long)(6 + i) * nx + x] = lat[kn[3 + i] * plane + t2];
+  }
 }
 
 // Folds a step's block partials into its slab sum (after the last step of a run).

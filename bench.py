@@ -98,29 +98,36 @@ def measure(name, world, rank, local_rank, uid, steps, warmup):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, gpu_ms = t[0].item(), t[1].item()
     vw = int(lat.info("vector_width"))
+    tb = int(lat.info("time_block_active"))              # 2: two steps per launch (lbm_sweep2)
     lat.close()
     cells = p.nx * p.ny
     local_cells = p.nx * (r1 - r0)
-    launch_s = gpu_ms * 1e-3 / steps                     # mean duration of one step's launch(es) on this GPU
-    achieved = BYTES_PER_LUP * local_cells / launch_s / 1e9
+    kernel = "lbm_sweep2<64,16>" if tb == 2 else f"lbm_sweep<{vw}>"
+    launches = steps // tb + steps % tb
+    launch_s = gpu_ms * 1e-3 / launches                  # mean duration of one launch on this GPU
+    bytes_per_launch = BYTES_PER_LUP * local_cells * steps / launches   # algorithmic bytes one launch covers
+    achieved = bytes_per_launch / launch_s / 1e9
     return {
         "mlups": cells * steps / dt / 1e6,
         "ms_per_step": dt * 1e3 / steps,
         "gpu_ms_per_step": gpu_ms / steps,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": lookup_traffic(name, world),
-                     "kernel": f"lbm_sweep<{vw}>", "bytes_per_launch": BYTES_PER_LUP * local_cells},
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": lookup_traffic(name, world, kernel),
+                     "kernel": kernel, "lattice_updates_per_launch": local_cells * steps / launches,
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "launch_us": round(launch_s * 1e6, 3)},
         "data": data, "params": p, "blocked": int(ob.sum()), "av_last": float(av[-1]), "finite": bool(np.isfinite(av).all()),
     }
 
 
-def lookup_traffic(name, world):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json), or None."""
+def lookup_traffic(name, world, kernel):
+    """HBM bytes per launch of `kernel` on workload `name` from the committed rocprofv3 PMC passes
+    (profiles/hbm_traffic.json, written by tools/summarize_profile.py), or None."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if world != 1 or not os.path.exists(path):
         return None
     try:
-        return json.load(open(path)).get(name, {}).get("hbm_bytes_per_launch")
+        return json.load(open(path)).get(name, {}).get(kernel.split("<")[0], {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
 

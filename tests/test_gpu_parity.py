@@ -262,23 +262,31 @@ def test_mass_is_conserved(gpu):
     assert abs(m1 - m0) < 3e-5 * m0
 
 
-@pytest.mark.parametrize("deck,nslabs", [("128x256", 2), ("128x256", 3), ("128x128", 4), ("128x128", 8),
-                                          ("1024x1024", 8)])
-def test_row_slabs_equal_single_slab(gpu, deck, nslabs):
+@pytest.mark.parametrize("deck,nslabs,time_block", [
+    ("128x256", 2, 2), ("128x256", 3, 2), ("128x128", 4, 2), ("128x128", 8, 2), ("1024x1024", 8, 2),
+    ("128x256", 2, 1), ("128x128", 8, 1), ("1024x1024", 4, 1)])
+def test_row_slabs_equal_single_slab(gpu, deck, nslabs, time_block):
     """Slab decomposition with halo exchange (peer-copy transport, all slabs on this one GPU):
-    the lattice must equal the undecomposed run bit for bit; av_vels differ only by summation order."""
+    the lattice must equal the undecomposed run bit for bit; av_vels differ only by summation order.
+    time_block 2: slabs whose rows tile by 16 run the two-step kernel with nine-slot halos every
+    second step (edge tile rows, exchange, interior tile rows); 3 slabs of 256 rows do not tile and
+    fall back to one-row halos every step."""
     L = gpu
     pf, of = deck_paths(deck)
     p = L.read_params(pf)
     ob = L.read_obstacles(of, p)
-    n = 60
+    n = 61
     with L.Lattice(p, ob) as lat:
+        lat.set_option("time_block", 1)
         av1 = np.concatenate([lat.run(n), lat.run(3)])
         st1 = lat.read_state()
         re1 = lat.reynolds()
     with L.Lattice(p, ob, nslabs=nslabs, devices=[0] * nslabs, exchange=L.EXCHANGE_COPY) as lat:
+        lat.set_option("time_block", time_block)
         assert lat.num_slabs == nslabs and lat.info("exchange") == L.EXCHANGE_COPY
         assert [lat.slab_rows(i) for i in range(nslabs)] == [L.slab_bounds(p.ny, nslabs, i) for i in range(nslabs)]
+        tiles = p.nx % 64 == 0 and p.ny % (16 * nslabs) == 0
+        assert lat.info("time_block_active") == (2 if time_block == 2 and tiles else 1)
         av2 = np.concatenate([lat.run(n), lat.run(3)])
         st2 = lat.read_state()
         re2 = lat.reynolds()
@@ -320,17 +328,21 @@ def test_rccl_transport_single_rank_ring(gpu):
     os.environ["LBM_FORCE_EXCHANGE"] = "1"
     try:
         with L.Lattice(p, ob, exchange=L.EXCHANGE_RCCL) as lat:
-            assert lat.info("exchange") == L.EXCHANGE_RCCL
-            av2 = lat.run(40)
+            assert lat.info("exchange") == L.EXCHANGE_RCCL and lat.info("time_block_active") == 2
+            av2 = lat.run(40)                       # nine-slot halos, every second step
             st2 = lat.read_state()
         uid = L.rccl_unique_id()
         with L.Lattice(p, ob, rank=0, nranks=1, device=0, unique_id=uid) as lat:
             assert lat.info("exchange") == L.EXCHANGE_RCCL
-            av3 = np.concatenate([lat.run(25), lat.run(15)])
+            av3 = np.concatenate([lat.run(25), lat.run(15)])   # odd run: trailing single step
             st3 = lat.read_state()
+        with L.Lattice(p, ob, rank=0, nranks=1, device=0, unique_id=L.rccl_unique_id()) as lat:
+            lat.set_option("time_block", 1)         # three-slot halos, every step
+            av4 = lat.run(40)
+            st4 = lat.read_state()
     finally:
         del os.environ["LBM_FORCE_EXCHANGE"]
-    for av, st in ((av2, st2), (av3, st3)):
+    for av, st in ((av2, st2), (av3, st3), (av4, st4)):
         assert np.array_equal(st1.view(np.uint32), st.view(np.uint32))
         assert np.allclose(av1, av, rtol=2e-6, atol=0)
 

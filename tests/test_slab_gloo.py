@@ -80,6 +80,105 @@ def _worker(rank, world, port, deck, nsteps, outdir):
         dist.destroy_process_group()
 
 
+def _worker_pairs(rank, world, port, deck, npairs, outdir):
+    """Two steps per halo exchange, two halo rows per side holding only the nine slots the
+    two-step kernel trades (everything else NaN)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import advanced_hpc_lbm_amd as L
+    import lbm_oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = O.Oracle("strict")
+        pf, of = deck
+        gp = O.read_params(pf)
+        gob = O.read_obstacles(of, gp.nx, gp.ny)
+        nx, ny = gp.nx, gp.ny
+        r0, r1 = L.slab_bounds(ny, world, rank)
+        nyl = r1 - r0
+        south, north = L.ring_neighbours(rank, world)
+        # ext rows: 0 <-> local -2, 1 <-> -1, 2..nyl+1 <-> own rows, nyl+2 <-> nyl, nyl+3 <-> nyl+1
+        lp = O.OrcParam(nx, nyl + 4, gp.maxIters, gp.reynolds_dim, gp.density, gp.accel, gp.omega)
+        ob = np.zeros((nyl + 4, nx), np.int32)
+        ob[2:nyl + 2] = gob[r0:r1]
+        ob[1] = gob[(r0 - 1) % ny]          # the ring rows' blocked maps (static, known at create)
+        ob[nyl + 2] = gob[r1 % ny]
+        a = np.full((nyl + 4, nx, 9), np.nan)
+        a[2:nyl + 2] = orc.init_cells(gp, np.float64)[r0:r1]
+        b = np.full_like(a, np.nan)
+
+        def ext_row_of_global(g):   # ext index of global row g if it is an own or ring row, else None
+            for e in range(1, nyl + 3):
+                if (r0 - 2 + e) % ny == g:
+                    return e
+            return None
+
+        acc_e = ext_row_of_global(ny - 2)
+        own_acc = acc_e if acc_e is not None and 2 <= acc_e <= nyl + 1 else None
+        av = np.zeros(2 * npairs)
+        for j in range(npairs):
+            if own_acc is not None:                   # accelerate of the pair's first step (own row only;
+                orc.accelerate_row(lp, a, ob, own_acc)  # the neighbours see it through the halo)
+            a[0:2] = np.nan
+            a[nyl + 2:] = np.nan
+            send_s = torch.from_numpy(np.stack([a[2 + dr][:, k] for dr, k in L.HALO9_TO_SOUTH]))
+            send_n = torch.from_numpy(np.stack([a[nyl + 1 - dr][:, k] for dr, k in L.HALO9_TO_NORTH]))
+            recv_n, recv_s = torch.empty_like(send_s), torch.empty_like(send_n)
+            reqs = [dist.isend(send_s, south, tag=1), dist.isend(send_n, north, tag=2),
+                    dist.irecv(recv_n, north, tag=1), dist.irecv(recv_s, south, tag=2)]
+            for r in reqs:
+                r.wait()
+            for slot, (dr, k) in enumerate(L.HALO9_TO_SOUTH):   # from the north: its rows 0, 1 = my nyl, nyl+1
+                a[nyl + 2 + dr][:, k] = recv_n[slot].numpy()
+            for slot, (dr, k) in enumerate(L.HALO9_TO_NORTH):   # from the south: its top rows = my -1, -2
+                a[1 - dr][:, k] = recv_s[slot].numpy()
+            # first step: own rows (counted) + the two ring rows (recomputed, not counted)
+            b[:] = np.nan
+            orc.sweep_rows(lp, a, b, ob, 1, 2)
+            tot, cnt = orc.sweep_rows(lp, a, b, ob, 2, nyl + 2)
+            orc.sweep_rows(lp, a, b, ob, nyl + 2, nyl + 3)
+            red = torch.tensor([tot, float(cnt)], dtype=torch.float64)
+            dist.all_reduce(red)
+            av[2 * j] = red[0].item() / red[1].item()
+            if acc_e is not None:                     # accelerate of the second step, ring rows included
+                orc.accelerate_row(lp, b, ob, acc_e)
+            a[:] = np.nan
+            tot, cnt = orc.sweep_rows(lp, b, a, ob, 2, nyl + 2)
+            red = torch.tensor([tot, float(cnt)], dtype=torch.float64)
+            dist.all_reduce(red)
+            av[2 * j + 1] = red[0].item() / red[1].item()
+        np.save(os.path.join(outdir, f"state_{rank}.npy"), a[2:nyl + 2])
+        np.save(os.path.join(outdir, f"av_{rank}.npy"), av)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,deck,npairs", [(2, "128x256", 15), (2, "128x128", 15), (3, "128x128", 8)])
+def test_two_step_halo_protocol_matches_single_domain_oracle(tmp_path, O, oracle, world, deck, npairs):
+    """The nine-slot halo of the two-step kernel (HALO9_*): exchanged once per pair of steps, ring rows
+    recomputed on both sides -- sufficient (all else is NaN) and bit-exact against the single domain."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.start_processes(_worker_pairs, args=(world, port, deck_paths(deck), npairs, str(tmp_path)),
+                       nprocs=world, join=True, start_method="spawn")
+    pf, of = deck_paths(deck)
+    prm = O.read_params(pf)
+    ob = O.read_obstacles(of, prm.nx, prm.ny)
+    cells = oracle.init_cells(prm, np.float64)
+    av = oracle.run(prm, cells, ob, 2 * npairs)
+    import advanced_hpc_lbm_amd as L
+    for r in range(world):
+        r0, r1 = L.slab_bounds(prm.ny, world, r)
+        got = np.load(tmp_path / f"state_{r}.npy")
+        assert np.array_equal(got, cells[r0:r1]), f"slab {r} differs from the single-domain lattice"
+        assert np.allclose(np.load(tmp_path / f"av_{r}.npy"), av, rtol=1e-12, atol=0)
+
+
 @pytest.mark.parametrize("world,deck,nsteps", [(2, "128x256", 40), (2, "128x128", 40), (3, "128x128", 25)])
 def test_slab_protocol_matches_single_domain_oracle(tmp_path, O, oracle, world, deck, nsteps):
     import torch.multiprocessing as mp

@@ -63,6 +63,7 @@ static void launch2(const Lat& L, int cur, int q, hipStream_t st, bool accel) {
   a.accel_row = L.ny - 2; a.accel_out = accel ? 1 : 0; a.a1 = 0.1f * 0.01f / 9.f; a.a2 = 0.1f * 0.01f / 36.f;
   a.partials1 = L.partials[q]; a.partials2 = L.partials[q] + (long)L.nx * L.ny / 512;
   a.prev1 = a.prev2 = nullptr;
+  a.by_begin = 0; a.by_count = L.ny / TY; a.by_stride = 1;
   const int grid = (L.nx / TX) * (L.ny / TY);
   hipLaunchKernelGGL((lbm::lbm_sweep2<TX, TY, MODE>), dim3(grid), dim3(lbm::kBlock), 0, st, a);
 }

@@ -45,20 +45,29 @@ if len(sys.argv) >= 5:
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if "lbm_sweep" in r["Kernel_Name"] and r["Counter_Name"] == which:
-                agg[int(r["Grid_Size"])].append(float(r["Counter_Value"]))
-        for g, v in agg.items():
+                kern = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("lbm::", "").split("<")[0]
+                agg[(kern, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+        for key, v in agg.items():
             v.sort()
-            vals.setdefault(g, {})[which] = v[len(v) // 2]
-    # grid size (threads) -> workload name: threads = cells / cells-per-thread
-    traffic = {}
-    for g, c in sorted(vals.items()):
+            vals.setdefault(key, {})[which] = v[len(v) // 2]
+    # (kernel, grid threads) -> workload: lbm_sweep covers cells/V cells per thread (V in 1,2,4),
+    # lbm_sweep2 covers 4 cells per thread and TWO steps per launch
+    path = os.path.join(out, "hbm_traffic.json")
+    traffic = json.load(open(path)) if os.path.exists(path) else {}
+    for (kern, g), c in sorted(vals.items()):
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            continue
         fetch_b = 2.0 * c["FETCH_SIZE"] * 1024.0
         write_b = c["WRITE_SIZE"] * 1024.0
         for name, cells in (("1024x1024", 1024 * 1024), ("8192x8192", 8192 * 8192)):
             if cells % g == 0 and cells // g in (1, 2, 4):
-                traffic[name] = {"grid_threads": g, "FETCH_SIZE_KiB_raw": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"],
-                                 "fetch_bytes_corrected_x2": fetch_b, "write_bytes": write_b,
-                                 "hbm_bytes_per_launch": fetch_b + write_b, "algorithmic_bytes_per_launch": 72.0 * cells,
-                                 "round": tag}
-    json.dump(traffic, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
+                steps = 2 if kern == "lbm_sweep2" else 1
+                traffic.setdefault(name, {})[kern] = {
+                    "grid_threads": g, "steps_per_launch": steps,
+                    "FETCH_SIZE_KiB_raw": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"],
+                    "fetch_bytes_corrected_x2": fetch_b, "write_bytes": write_b,
+                    "hbm_bytes_per_launch": fetch_b + write_b,
+                    "algorithmic_bytes_per_launch": 72.0 * cells * steps,
+                    "hbm_bytes_per_lattice_update": (fetch_b + write_b) / (cells * steps), "round": tag}
+    json.dump(traffic, open(path, "w"), indent=1)
     print(json.dumps(traffic, indent=1))
