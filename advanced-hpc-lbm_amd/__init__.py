@@ -31,11 +31,12 @@ LIB_PATH = os.path.join(_HERE, "liblbm_mi355x.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lbm_mi355x.h")
 
 NSPEEDS = 9
-EXCHANGE_AUTO, EXCHANGE_COPY, EXCHANGE_RCCL = 0, 1, 2
+EXCHANGE_AUTO, EXCHANGE_COPY, EXCHANGE_RCCL, EXCHANGE_P2P = 0, 1, 2, 3
 
 # every symbol include/lbm_mi355x.h declares
 ABI_SYMBOLS = (
     "lbm_last_error", "lbm_device_count", "lbm_create", "lbm_rccl_unique_id", "lbm_create_rank",
+    "lbm_create_rank_ex", "lbm_p2p_handle", "lbm_p2p_connect",
     "lbm_slab_rows", "lbm_num_slabs", "lbm_run", "lbm_last_run_ms", "lbm_read_state",
     "lbm_av_velocity", "lbm_reynolds", "lbm_total_density", "lbm_final_state", "lbm_destroy",
     "lbm_timestep", "lbm_set_option", "lbm_get_info",
@@ -80,6 +81,9 @@ def load_library():
     lib.lbm_create.argtypes = [C.POINTER(Param), vp, vp, C.c_int, vp, C.c_int, C.POINTER(vp)]
     lib.lbm_rccl_unique_id.argtypes = [vp]
     lib.lbm_create_rank.argtypes = [C.POINTER(Param), vp, vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    lib.lbm_create_rank_ex.argtypes = [C.POINTER(Param), vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
+    lib.lbm_p2p_handle.argtypes = [vp, vp]
+    lib.lbm_p2p_connect.argtypes = [vp, vp, C.c_int]
     lib.lbm_slab_rows.argtypes = [vp, C.c_int, ip, ip]
     lib.lbm_num_slabs.argtypes = [vp]
     lib.lbm_run.argtypes = [vp, C.c_int, vp]
@@ -155,9 +159,25 @@ class Lattice:
                                         C.byref(self._ctx)))
         else:
             idbuf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
-            _check(self._lib.lbm_create_rank(C.byref(params), ob.ctypes.data, cp, rank, nranks, device,
-                                             idbuf, C.byref(self._ctx)))
+            if exchange == EXCHANGE_AUTO:
+                _check(self._lib.lbm_create_rank(C.byref(params), ob.ctypes.data, cp, rank, nranks, device,
+                                                 idbuf, C.byref(self._ctx)))
+            else:
+                _check(self._lib.lbm_create_rank_ex(C.byref(params), ob.ctypes.data, cp, rank, nranks, device,
+                                                    idbuf, exchange, C.byref(self._ctx)))
         self.rank_mode = rank is not None
+
+    # -- peer-to-peer halos without RCCL: the caller trades the handles ------------
+    def p2p_handle(self) -> bytes:
+        buf = C.create_string_buffer(64)
+        _check(self._lib.lbm_p2p_handle(self._ctx, buf))
+        return buf.raw
+
+    def p2p_connect(self, handles):
+        """handles: the 64-byte handles of all ranks, in rank order."""
+        blob = b"".join(handles)
+        buf = C.create_string_buffer(blob, len(blob))
+        _check(self._lib.lbm_p2p_connect(self._ctx, buf, len(handles)))
 
     # -- the step loop -----------------------------------------------------
     def run(self, nsteps: int) -> np.ndarray:

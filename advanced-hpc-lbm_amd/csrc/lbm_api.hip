@@ -53,7 +53,7 @@ extern "C" const char* lbm_last_error(void) { return g_err; }
 namespace rccl {
 typedef struct ncclComm* comm_t;
 struct unique_id { char internal[128]; };
-enum { kFloat32 = 7, kFloat64 = 8, kSum = 0 };
+enum { kInt8 = 0, kFloat32 = 7, kFloat64 = 8, kSum = 0 };
 static int (*GetUniqueId)(unique_id*);
 static int (*CommInitRank)(comm_t*, int, unique_id, int);
 static int (*CommInitAll)(comm_t*, int, const int*);
@@ -63,6 +63,7 @@ static int (*Recv)(void*, size_t, int, int, comm_t, hipStream_t);
 static int (*GroupStart)();
 static int (*GroupEnd)();
 static int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t);
+static int (*AllGather)(const void*, void*, size_t, int, comm_t, hipStream_t);
 static const char* (*GetErrorString)(int);
 static void* handle = nullptr;
 
@@ -86,6 +87,7 @@ static int load() {
   SYM(GroupStart, "ncclGroupStart");
   SYM(GroupEnd, "ncclGroupEnd");
   SYM(AllReduce, "ncclAllReduce");
+  SYM(AllGather, "ncclAllGather");
   SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
   return LBM_OK;
@@ -121,11 +123,22 @@ struct Slab {
   int sums_cap = 0;
   double* scratch_d = nullptr; // small double scratch (derive / reductions)
   int scratch_cap = 0;
-  hipStream_t sc = nullptr, sx = nullptr;
-  hipEvent_t ev_bnd[2] = {nullptr, nullptr}, ev_recv[2] = {nullptr, nullptr};
+  // sc: interior launches (and everything outside the step loop); se: edge launches, higher
+  // priority, concurrent with the interior launch of the same step; sx: halo exchange
+  hipStream_t sc = nullptr, se = nullptr, sx = nullptr;
+  hipEvent_t ev_bnd[2] = {nullptr, nullptr}, ev_recv[2] = {nullptr, nullptr}, ev_int[2] = {nullptr, nullptr};
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
   int accel_row = -1;          // local index of global row ny-2, or -1
   rccl::comm_t comm = nullptr;
+  // peer-to-peer halos (LBM_EXCHANGE_P2P): one uncached block holds ghost_s[2], ghost_n[2] and the
+  // two flags the neighbours raise; the neighbours' blocks are mapped here (peer access or hipIpc)
+  char* comm_block = nullptr;
+  size_t halo_bytes = 0;       // one nine-slot halo buffer, rounded up to 256 B
+  char* peer_s = nullptr;      // south / north neighbour's comm block as seen from this device
+  char* peer_n = nullptr;
+  bool peer_s_ipc = false, peer_n_ipc = false;
+  uint32_t* counters = nullptr;  // device: [0] cnt_s, [16] cnt_n, [32] err (separate 64-B lines)
+  uint32_t cnt_s_total = 0, cnt_n_total = 0;
 };
 
 }  // namespace
@@ -141,6 +154,9 @@ struct lbm_ctx {
   int V = 1;                   // cells per thread
   long variant = 0;
   int time_block = 1;          // 2: fuse pairs of steps through LDS (lbm_sweep2) where eligible
+  uint32_t seq = 0;            // peer-to-peer: sequence number of the last launch group (same on all slabs)
+  bool p2p_connected = false;
+  bool no_comm = false;        // rank mode without RCCL: results are this rank's contribution
   double gpu_ms = 0.0, wall_ms = 0.0;
 };
 
@@ -159,6 +175,63 @@ int pick_vector_width(int nx) {
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Halo buffers of a slab for the context's exchange mode (callable again after a fallback from
+// peer-to-peer to RCCL: slab_free_halos first).
+void slab_free_halos(Slab& s) {
+  (void)hipSetDevice(s.dev);
+  for (int i = 0; i < 2; ++i) {
+    if (s.ghost_s[i] && !s.comm_block) (void)hipFree(s.ghost_s[i]);
+    if (s.ghost_n[i] && !s.comm_block) (void)hipFree(s.ghost_n[i]);
+    if (s.send_s[i]) (void)hipFree(s.send_s[i]);
+    if (s.send_n[i]) (void)hipFree(s.send_n[i]);
+    s.ghost_s[i] = s.ghost_n[i] = s.send_s[i] = s.send_n[i] = nullptr;
+  }
+  if (s.blocked_gs) (void)hipFree(s.blocked_gs);
+  if (s.blocked_gn) (void)hipFree(s.blocked_gn);
+  s.blocked_gs = s.blocked_gn = nullptr;
+  if (s.peer_s_ipc && s.peer_s) (void)hipIpcCloseMemHandle(s.peer_s);
+  if (s.peer_n_ipc && s.peer_n && s.peer_n != s.peer_s) (void)hipIpcCloseMemHandle(s.peer_n);
+  s.peer_s = s.peer_n = nullptr; s.peer_s_ipc = s.peer_n_ipc = false;
+  if (s.comm_block) (void)hipFree(s.comm_block);
+  if (s.counters) (void)hipFree(s.counters);
+  s.comm_block = nullptr; s.counters = nullptr;
+}
+
+int slab_alloc_halos(lbm_ctx* c, Slab& s) {
+  HIPC(hipSetDevice(s.dev));
+  const int nx = c->p.nx;
+  const bool exchanging = true;
+  if (exchanging && c->exchange == LBM_EXCHANGE_P2P) {
+    HIPC(hipMalloc((void**)&s.blocked_gs, (size_t)nx));
+    HIPC(hipMalloc((void**)&s.blocked_gn, (size_t)nx));
+    s.halo_bytes = (sizeof(float) * lbm::kHaloSlots * (size_t)nx + 255) / 256 * 256;
+    const size_t total = 4 * s.halo_bytes + 512;
+    // uncached: the neighbours write it over xGMI behind this GPU's L2
+    hipError_t e = hipExtMallocWithFlags((void**)&s.comm_block, total, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags((void**)&s.comm_block, total, hipDeviceMallocFinegrained); }
+    if (e != hipSuccess) { (void)hipGetLastError(); s.comm_block = nullptr; return fail(LBM_EHIP, "cannot allocate uncached halo memory: %s", hipGetErrorString(e)); }
+    HIPC(hipMemset(s.comm_block, 0, total));
+    HIPC(hipMalloc((void**)&s.counters, 64 * sizeof(uint32_t)));
+    HIPC(hipMemset(s.counters, 0, 64 * sizeof(uint32_t)));
+    HIPC(hipDeviceSynchronize());
+    for (int i = 0; i < 2; ++i) {
+      s.ghost_s[i] = (float*)(s.comm_block + (size_t)i * s.halo_bytes);
+      s.ghost_n[i] = (float*)(s.comm_block + (size_t)(2 + i) * s.halo_bytes);
+    }
+  } else if (exchanging) {
+    const size_t hb = sizeof(float) * lbm::kHaloSlots * (size_t)nx;
+    HIPC(hipMalloc((void**)&s.blocked_gs, (size_t)nx));
+    HIPC(hipMalloc((void**)&s.blocked_gn, (size_t)nx));
+    for (int i = 0; i < 2; ++i) {
+      HIPC(hipMalloc((void**)&s.ghost_s[i], hb));
+      HIPC(hipMalloc((void**)&s.ghost_n[i], hb));
+      HIPC(hipMalloc((void**)&s.send_s[i], hb));
+      HIPC(hipMalloc((void**)&s.send_n[i], hb));
+    }
+  }
+  return LBM_OK;
+}
+
 int slab_alloc(lbm_ctx* c, Slab& s, bool exchanging) {
   HIPC(hipSetDevice(s.dev));
   const int nx = c->p.nx;
@@ -175,28 +248,38 @@ int slab_alloc(lbm_ctx* c, Slab& s, bool exchanging) {
   for (int i = 0; i < 2; ++i) HIPC(hipMalloc((void**)&s.partials[i], sizeof(float) * s.partial_cap));
   s.scratch_cap = s.partial_cap;
   HIPC(hipMalloc((void**)&s.scratch_d, sizeof(double) * (s.scratch_cap + 8)));
-  if (exchanging) {
-    const size_t hb = sizeof(float) * lbm::kHaloSlots * (size_t)nx;
-    HIPC(hipMalloc((void**)&s.blocked_gs, (size_t)nx));
-    HIPC(hipMalloc((void**)&s.blocked_gn, (size_t)nx));
-    for (int i = 0; i < 2; ++i) {
-      HIPC(hipMalloc((void**)&s.ghost_s[i], hb));
-      HIPC(hipMalloc((void**)&s.ghost_n[i], hb));
-      HIPC(hipMalloc((void**)&s.send_s[i], hb));
-      HIPC(hipMalloc((void**)&s.send_n[i], hb));
-    }
-  }
+  if (exchanging) { int rc = slab_alloc_halos(c, s); if (rc) return rc; }
   HIPC(hipStreamCreateWithFlags(&s.sc, hipStreamNonBlocking));
-  HIPC(hipStreamCreateWithFlags(&s.sx, hipStreamNonBlocking));
+  {
+    int lo = 0, hi = 0;  // numerically lower = higher priority
+    HIPC(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPC(hipStreamCreateWithPriority(&s.se, hipStreamNonBlocking, hi));
+    HIPC(hipStreamCreateWithPriority(&s.sx, hipStreamNonBlocking, hi));
+  }
   // everything that touches slab memory is ordered on s.sc (the streams are
   // non-blocking: a null-stream memset would race with the first kernels)
   HIPC(hipMemsetAsync(s.blocked, 0, (size_t)s.plane, s.sc));
   for (int i = 0; i < 2; ++i) {
     HIPC(hipEventCreateWithFlags(&s.ev_bnd[i], hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&s.ev_recv[i], hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&s.ev_int[i], hipEventDisableTiming));
   }
   HIPC(hipEventCreate(&s.ev_t0));
   HIPC(hipEventCreate(&s.ev_t1));
+  return LBM_OK;
+}
+
+// Blocked maps of the two rows just outside the slab (periodic in the global lattice): the ring
+// rows of the two-step kernel.
+int upload_ghost_masks(lbm_ctx* c, Slab& s, const int* obstacles) {
+  HIPC(hipSetDevice(s.dev));
+  const int nx = c->p.nx, ny = c->p.ny;
+  const int rs = (s.row0 + ny - 1) % ny, rn = (s.row0 + s.nyl) % ny;
+  std::vector<uint8_t> gs(nx), gn(nx);
+  for (int x = 0; x < nx; ++x) { gs[x] = obstacles[(long)rs * nx + x] ? 1 : 0; gn[x] = obstacles[(long)rn * nx + x] ? 1 : 0; }
+  HIPC(hipMemcpyAsync(s.blocked_gs, gs.data(), nx, hipMemcpyHostToDevice, s.sc));
+  HIPC(hipMemcpyAsync(s.blocked_gn, gn.data(), nx, hipMemcpyHostToDevice, s.sc));
+  HIPC(hipStreamSynchronize(s.sc));
   return LBM_OK;
 }
 
@@ -212,15 +295,7 @@ int slab_upload(lbm_ctx* c, Slab& s, const int* obstacles, const float* cells) {
     HIPC(hipMemcpyAsync(d_ob, obstacles + (long)s.row0 * nx, sizeof(int) * ncell, hipMemcpyHostToDevice, s.sc));
     hipLaunchKernelGGL(lbm::lbm_pack_blocked, dim3(grid), dim3(256), 0, s.sc, d_ob, s.blocked, s.pitch, nx, ncell);
     HIPC(hipGetLastError());
-    if (s.blocked_gs) {  // rows just outside the slab (periodic in the global lattice)
-      const int ny = c->p.ny;
-      const int rs = (s.row0 + ny - 1) % ny, rn = (s.row0 + s.nyl) % ny;
-      std::vector<uint8_t> gs(nx), gn(nx);
-      for (int x = 0; x < nx; ++x) { gs[x] = obstacles[(long)rs * nx + x] ? 1 : 0; gn[x] = obstacles[(long)rn * nx + x] ? 1 : 0; }
-      HIPC(hipMemcpyAsync(s.blocked_gs, gs.data(), nx, hipMemcpyHostToDevice, s.sc));
-      HIPC(hipMemcpyAsync(s.blocked_gn, gn.data(), nx, hipMemcpyHostToDevice, s.sc));
-      HIPC(hipStreamSynchronize(s.sc));
-    }
+    if (s.blocked_gs) { int rc2 = upload_ghost_masks(c, s, obstacles); if (rc2) return rc2; }
     HIPC(hipStreamSynchronize(s.sc));
     HIPC(hipFree(d_ob));
   }
@@ -280,47 +355,45 @@ bool t2_eligible(const lbm_ctx* c) {
   return c->p.ny % (c->nranks * kT2Y) == 0;
 }
 
-template <int MODE, bool EDGE>
-void launch_sweep2_me(const lbm::Sweep2Args& a, int grid, hipStream_t st) {
-  hipLaunchKernelGGL((lbm::lbm_sweep2<kT2X, kT2Y, MODE, EDGE>), dim3(grid), dim3(lbm::kBlock), 0, st, a);
+template <int MODE, int KIND>
+void launch_sweep2_mk(const lbm::Sweep2Args& a, int grid, hipStream_t st) {
+  hipLaunchKernelGGL((lbm::lbm_sweep2<kT2X, kT2Y, MODE, KIND>), dim3(grid), dim3(lbm::kBlock), 0, st, a);
 }
 
-void launch_sweep2(const lbm_ctx* c, const lbm::Sweep2Args& a, int grid, hipStream_t st, bool edge) {
+template <int KIND>
+void launch_sweep2_k(const lbm_ctx* c, const lbm::Sweep2Args& a, int grid, hipStream_t st) {
   // cache-resident lattices: default policy; streamed lattices: nontemporal stores (kbench)
-  const int mode = (int)(c->variant & (lbm::kFastMath | lbm::kNtStore));
-  switch (mode * 2 + (edge ? 1 : 0)) {
-    case 0: launch_sweep2_me<0, false>(a, grid, st); break;
-    case 1: launch_sweep2_me<0, true>(a, grid, st); break;
-    case 2: launch_sweep2_me<1, false>(a, grid, st); break;
-    case 3: launch_sweep2_me<1, true>(a, grid, st); break;
-    case 4: launch_sweep2_me<2, false>(a, grid, st); break;
-    case 5: launch_sweep2_me<2, true>(a, grid, st); break;
-    case 6: launch_sweep2_me<3, false>(a, grid, st); break;
-    default: launch_sweep2_me<3, true>(a, grid, st); break;
+  switch ((int)(c->variant & (lbm::kFastMath | lbm::kNtStore))) {
+    case 0: launch_sweep2_mk<0, KIND>(a, grid, st); break;
+    case 1: launch_sweep2_mk<1, KIND>(a, grid, st); break;
+    case 2: launch_sweep2_mk<2, KIND>(a, grid, st); break;
+    default: launch_sweep2_mk<3, KIND>(a, grid, st); break;
   }
 }
 
+void launch_sweep2(const lbm_ctx* c, const lbm::Sweep2Args& a, int grid, hipStream_t st, bool edge) {
+  if (edge) launch_sweep2_k<lbm::kSweep2Edge>(c, a, grid, st);
+  else launch_sweep2_k<lbm::kSweep2Plain>(c, a, grid, st);
+}
+
 void slab_free(Slab& s) {
+  slab_free_halos(s);
   (void)hipSetDevice(s.dev);
   for (int i = 0; i < 2; ++i) {
     if (s.lat[i]) (void)hipFree(s.lat[i]);
     if (s.partials[i]) (void)hipFree(s.partials[i]);
-    if (s.ghost_s[i]) (void)hipFree(s.ghost_s[i]);
-    if (s.ghost_n[i]) (void)hipFree(s.ghost_n[i]);
-    if (s.send_s[i]) (void)hipFree(s.send_s[i]);
-    if (s.send_n[i]) (void)hipFree(s.send_n[i]);
     if (s.ev_bnd[i]) (void)hipEventDestroy(s.ev_bnd[i]);
     if (s.ev_recv[i]) (void)hipEventDestroy(s.ev_recv[i]);
+    if (s.ev_int[i]) (void)hipEventDestroy(s.ev_int[i]);
   }
   if (s.blocked) (void)hipFree(s.blocked);
-  if (s.blocked_gs) (void)hipFree(s.blocked_gs);
-  if (s.blocked_gn) (void)hipFree(s.blocked_gn);
   if (s.sums) (void)hipFree(s.sums);
   if (s.scratch_d) (void)hipFree(s.scratch_d);
   if (s.ev_t0) (void)hipEventDestroy(s.ev_t0);
   if (s.ev_t1) (void)hipEventDestroy(s.ev_t1);
   if (s.comm) (void)rccl::CommDestroy(s.comm);
   if (s.sc) (void)hipStreamDestroy(s.sc);
+  if (s.se) (void)hipStreamDestroy(s.se);
   if (s.sx) (void)hipStreamDestroy(s.sx);
 }
 
@@ -462,6 +535,76 @@ extern "C" int lbm_rccl_unique_id(void* id128) {
   return LBM_OK;
 }
 
+namespace {
+
+// Peer-to-peer: neighbour comm blocks of slabs that live in THIS process.
+int p2p_connect_local(lbm_ctx* c) {
+  const int ns = (int)c->slabs.size();
+  for (int i = 0; i < ns; ++i) {
+    Slab& s = c->slabs[i];
+    Slab& so = c->slabs[(i + ns - 1) % ns];
+    Slab& no = c->slabs[(i + 1) % ns];
+    for (Slab* o : {&so, &no}) {
+      if (o->dev == s.dev) continue;
+      int can = 0;
+      HIPC(hipDeviceCanAccessPeer(&can, s.dev, o->dev));
+      if (!can) return fail(LBM_EHIP, "device %d cannot access device %d peer-to-peer", s.dev, o->dev);
+      HIPC(hipSetDevice(s.dev));
+      hipError_t e = hipDeviceEnablePeerAccess(o->dev, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+        return fail(LBM_EHIP, "hipDeviceEnablePeerAccess(%d -> %d): %s", s.dev, o->dev, hipGetErrorString(e));
+      (void)hipGetLastError();
+    }
+    s.peer_s = so.comm_block;
+    s.peer_n = no.comm_block;
+  }
+  c->p2p_connected = true;
+  return LBM_OK;
+}
+
+// Peer-to-peer, one process per GPU: map the two neighbours' comm blocks from their hipIpc handles.
+int p2p_connect_ipc(lbm_ctx* c, const char* handles, int nranks) {
+  if (nranks != c->nranks) return fail(LBM_EINVAL, "expected %d handles, got %d", c->nranks, nranks);
+  Slab& s = c->slabs[0];
+  HIPC(hipSetDevice(s.dev));
+  const int south = (c->rank + nranks - 1) % nranks, north = (c->rank + 1) % nranks;
+  auto open = [&](int r, char** out, bool* ipc) -> int {
+    if (r == c->rank) { *out = s.comm_block; *ipc = false; return LBM_OK; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, handles + (size_t)r * LBM_P2P_HANDLE_BYTES, sizeof(h));
+    void* ptr = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(LBM_EHIP, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e)); }
+    *out = (char*)ptr; *ipc = true;
+    return LBM_OK;
+  };
+  int rc = open(south, &s.peer_s, &s.peer_s_ipc);
+  if (rc) return rc;
+  if (north == south) { s.peer_n = s.peer_s; s.peer_n_ipc = false; }
+  else if ((rc = open(north, &s.peer_n, &s.peer_n_ipc))) return rc;
+  c->p2p_connected = true;
+  return LBM_OK;
+}
+
+int p2p_export(lbm_ctx* c, char* handle64) {
+  Slab& s = c->slabs[0];
+  if (!s.comm_block) return fail(LBM_EINVAL, "context has no peer-to-peer halo block");
+  HIPC(hipSetDevice(s.dev));
+  hipIpcMemHandle_t h;
+  HIPC(hipIpcGetMemHandle(&h, s.comm_block));
+  memcpy(handle64, &h, LBM_P2P_HANDLE_BYTES);
+  return LBM_OK;
+}
+
+int create_fail(lbm_ctx* c, int rc) {
+  std::string keep = g_err;
+  lbm_destroy(c);
+  snprintf(g_err, sizeof(g_err), "%s", keep.c_str());
+  return rc;
+}
+
+}  // namespace
+
 extern "C" int lbm_create(const lbm_param* params, const int* obstacles, const float* cells,
                           int nslabs, const int* devices, int exchange, lbm_ctx** out) {
   if (!out) return fail(LBM_EINVAL, "out is NULL");
@@ -470,7 +613,7 @@ extern "C" int lbm_create(const lbm_param* params, const int* obstacles, const f
   if (rc) return rc;
   if (!obstacles) return fail(LBM_EINVAL, "obstacles is NULL");
   if (nslabs < 1 || nslabs > params->ny) return fail(LBM_EINVAL, "nslabs must be in [1, ny] (got %d)", nslabs);
-  if (exchange < 0 || exchange > 2) return fail(LBM_EINVAL, "unknown exchange mode %d", exchange);
+  if (exchange < 0 || exchange > LBM_EXCHANGE_P2P) return fail(LBM_EINVAL, "unknown exchange mode %d", exchange);
   int ndev = 0;
   lbm_device_count(&ndev);
   if (ndev < 1) return fail(LBM_ENODEV, "no HIP device visible; this library has no CPU path");
@@ -483,6 +626,10 @@ extern "C" int lbm_create(const lbm_param* params, const int* obstacles, const f
     c->exchange = 0;
   else
     c->exchange = (exchange == LBM_EXCHANGE_AUTO) ? LBM_EXCHANGE_RCCL : exchange;
+  if (c->exchange == LBM_EXCHANGE_P2P && params->ny / nslabs < 2) {
+    delete c;
+    return fail(LBM_EINVAL, "peer-to-peer halos need at least 2 rows per slab");
+  }
   c->tot_fluid = count_fluid(obstacles, (long)params->nx * params->ny);
   c->slabs.resize(nslabs);
   std::vector<int> devs(nslabs);
@@ -507,13 +654,15 @@ extern "C" int lbm_create(const lbm_param* params, const int* obstacles, const f
       else for (int i = 0; i < nslabs; ++i) c->slabs[i].comm = comms[i];
     }
   }
-  if (rc) { std::string keep = g_err; lbm_destroy(c); snprintf(g_err, sizeof(g_err), "%s", keep.c_str()); return rc; }
+  if (!rc && c->exchange == LBM_EXCHANGE_P2P) rc = p2p_connect_local(c);
+  if (rc) return create_fail(c, rc);
   *out = c;
   return LBM_OK;
 }
 
-extern "C" int lbm_create_rank(const lbm_param* params, const int* obstacles, const float* cells,
-                               int rank, int nranks, int device, const void* unique_id, lbm_ctx** out) {
+extern "C" int lbm_create_rank_ex(const lbm_param* params, const int* obstacles, const float* cells,
+                                  int rank, int nranks, int device, const void* unique_id, int exchange,
+                                  lbm_ctx** out) {
   if (!out) return fail(LBM_EINVAL, "out is NULL");
   *out = nullptr;
   int rc = check_params(params);
@@ -521,28 +670,47 @@ extern "C" int lbm_create_rank(const lbm_param* params, const int* obstacles, co
   if (!obstacles) return fail(LBM_EINVAL, "obstacles is NULL");
   if (nranks < 1 || nranks > params->ny || rank < 0 || rank >= nranks)
     return fail(LBM_EINVAL, "bad rank %d of %d (ny = %d)", rank, nranks, params->ny);
+  if (exchange != LBM_EXCHANGE_RCCL && exchange != LBM_EXCHANGE_P2P)
+    return fail(LBM_EINVAL, "rank contexts trade halos by RCCL or peer-to-peer (got mode %d)", exchange);
   int ndev = 0;
   lbm_device_count(&ndev);
   if (ndev < 1) return fail(LBM_ENODEV, "no HIP device visible; this library has no CPU path");
   if (device < 0 || device >= ndev) return fail(LBM_ENODEV, "HIP device %d not visible (%d devices)", device, ndev);
   const char* force = getenv("LBM_FORCE_EXCHANGE");
   const bool exchanging = nranks > 1 || (force && atoi(force));
-  if (exchanging && !unique_id) return fail(LBM_EINVAL, "unique_id is NULL");
+  const bool want_p2p = exchanging && exchange == LBM_EXCHANGE_P2P;
+  if (exchanging && !unique_id && !want_p2p) return fail(LBM_EINVAL, "unique_id is NULL");
+  if (want_p2p && params->ny / nranks < 2) return fail(LBM_EINVAL, "peer-to-peer halos need at least 2 rows per slab");
 
   lbm_ctx* c = new lbm_ctx();
   c->p = *params;
   c->rank_mode = true;
   c->rank = rank;
   c->nranks = nranks;
-  c->exchange = exchanging ? LBM_EXCHANGE_RCCL : 0;
+  c->exchange = exchanging ? (want_p2p ? LBM_EXCHANGE_P2P : LBM_EXCHANGE_RCCL) : 0;
+  c->no_comm = (unique_id == nullptr) && nranks > 1;
   c->tot_fluid = count_fluid(obstacles, (long)params->nx * params->ny);
   c->slabs.resize(1);
   Slab& s = c->slabs[0];
   s.dev = device;
   s.row0 = (int)((long)rank * params->ny / nranks);
   s.nyl = (int)((long)(rank + 1) * params->ny / nranks) - s.row0;
+  int p2p_rc = LBM_OK;   // a failed peer-to-peer set-up is survivable when RCCL is there to fall back on
+  if (want_p2p && unique_id) {
+    // probe the uncached allocation first, so that a refusal does not abort the slab set-up half way
+    void* probe = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipExtMallocWithFlags(&probe, 4096, hipDeviceMallocUncached) != hipSuccess) {
+      (void)hipGetLastError();
+      if (hipExtMallocWithFlags(&probe, 4096, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        p2p_rc = fail(LBM_EHIP, "uncached / fine-grained device memory not available");
+        c->exchange = LBM_EXCHANGE_RCCL;
+      }
+    }
+    if (probe) (void)hipFree(probe);
+  }
   rc = finish_create(c, obstacles, cells);
-  if (!rc && (exchanging || nranks > 1)) {
+  if (!rc && unique_id && (exchanging || nranks > 1)) {
     rc = rccl::load();
     if (!rc) {
       rccl::unique_id id;
@@ -554,9 +722,64 @@ extern "C" int lbm_create_rank(const lbm_param* params, const int* obstacles, co
       }
     }
   }
-  if (rc) { std::string keep = g_err; lbm_destroy(c); snprintf(g_err, sizeof(g_err), "%s", keep.c_str()); return rc; }
+  if (!rc && want_p2p && unique_id) {
+    // trade the hipIpc handles through the communicator; every rank learns whether ALL succeeded
+    const size_t hb = LBM_P2P_HANDLE_BYTES;
+    std::vector<char> all((size_t)nranks * hb, 0), mine(hb, 0);
+    if (!p2p_rc && nranks > 1) p2p_rc = p2p_export(c, mine.data());
+    char* d_buf = nullptr;
+    if (hipMalloc((void**)&d_buf, (size_t)(nranks + 1) * hb) != hipSuccess) rc = fail(LBM_EHIP, "hipMalloc failed");
+    if (!rc) {
+      (void)hipMemcpy(d_buf + (size_t)nranks * hb, mine.data(), hb, hipMemcpyHostToDevice);
+      int r = rccl::AllGather(d_buf + (size_t)nranks * hb, d_buf, hb, rccl::kInt8, s.comm, s.sc);
+      if (r != 0) rc = fail(LBM_ERCCL, "ncclAllGather failed: %s", rccl::GetErrorString(r));
+      if (!rc && hipStreamSynchronize(s.sc) != hipSuccess) rc = fail(LBM_EHIP, "handle all-gather failed");
+      if (!rc) (void)hipMemcpy(all.data(), d_buf, (size_t)nranks * hb, hipMemcpyDeviceToHost);
+    }
+    if (!rc && !p2p_rc) p2p_rc = (nranks > 1) ? p2p_connect_ipc(c, all.data(), nranks) : p2p_connect_local(c);
+    if (!rc) {  // agreement: sum of failures over all ranks
+      double fails = p2p_rc ? 1.0 : 0.0, *d_f = (double*)d_buf;
+      (void)hipMemcpy(d_f, &fails, sizeof(double), hipMemcpyHostToDevice);
+      int r = rccl::AllReduce(d_f, d_f, 1, rccl::kFloat64, rccl::kSum, s.comm, s.sc);
+      if (r != 0 || hipStreamSynchronize(s.sc) != hipSuccess) rc = fail(LBM_ERCCL, "peer-to-peer agreement failed");
+      else (void)hipMemcpy(&fails, d_f, sizeof(double), hipMemcpyDeviceToHost);
+      if (!rc && fails > 0.0) {
+        // somebody could not map a neighbour: everyone trades halos by RCCL instead
+        if (getenv("LBM_VERBOSE")) fprintf(stderr, "lbm: peer-to-peer halos unavailable (%s); using RCCL\n", p2p_rc ? g_err : "another rank failed");
+        slab_free_halos(s);
+        c->exchange = LBM_EXCHANGE_RCCL;
+        c->p2p_connected = false;
+        rc = slab_alloc_halos(c, s);
+        if (!rc) rc = upload_ghost_masks(c, s, obstacles);
+      }
+    }
+    if (d_buf) (void)hipFree(d_buf);
+  } else if (!rc && want_p2p && nranks == 1) {
+    rc = p2p_connect_local(c);   // ring of one (LBM_FORCE_EXCHANGE)
+  }
+  if (rc) return create_fail(c, rc);
   *out = c;
   return LBM_OK;
+}
+
+extern "C" int lbm_create_rank(const lbm_param* params, const int* obstacles, const float* cells,
+                               int rank, int nranks, int device, const void* unique_id, lbm_ctx** out) {
+  const char* e = getenv("LBM_RANK_EXCHANGE");
+  const int mode = (e && !strcmp(e, "p2p")) ? LBM_EXCHANGE_P2P : LBM_EXCHANGE_RCCL;
+  return lbm_create_rank_ex(params, obstacles, cells, rank, nranks, device, unique_id, mode, out);
+}
+
+extern "C" int lbm_p2p_handle(lbm_ctx* c, void* handle64) {
+  if (!c || !handle64) return fail(LBM_EINVAL, "NULL argument");
+  if (!c->rank_mode || c->exchange != LBM_EXCHANGE_P2P) return fail(LBM_EINVAL, "not a peer-to-peer rank context");
+  return p2p_export(c, (char*)handle64);
+}
+
+extern "C" int lbm_p2p_connect(lbm_ctx* c, const void* handles, int nranks) {
+  if (!c || !handles) return fail(LBM_EINVAL, "NULL argument");
+  if (!c->rank_mode || c->exchange != LBM_EXCHANGE_P2P) return fail(LBM_EINVAL, "not a peer-to-peer rank context");
+  if (c->p2p_connected) return fail(LBM_EINVAL, "already connected");
+  return p2p_connect_ipc(c, (const char*)handles, nranks);
 }
 
 extern "C" int lbm_num_slabs(const lbm_ctx* ctx) { return ctx ? (int)ctx->slabs.size() : 0; }
@@ -569,6 +792,12 @@ extern "C" int lbm_slab_rows(const lbm_ctx* ctx, int slab, int* row_begin, int* 
 }
 
 namespace {
+
+// Edge launches run on their own high-priority stream, concurrent with the interior launch, only
+// when the interior is long enough to pay for the extra cross-stream events (measured on one GPU,
+// RCCL self-ring: 8192^2 577 -> 537 us/step, but 1024^2 24 -> 33 us/step): big slabs only.
+inline bool split_edge_stream(const lbm_ctx* c, const Slab& s) { return (long)s.nyl * c->p.nx >= (1L << 22); }
+inline hipStream_t edge_stream(const lbm_ctx* c, const Slab& s) { return split_edge_stream(c, s) ? s.se : s.sc; }
 
 // One single-step launch group (all local slabs) for step tt, launch index li.
 int launch_single(lbm_ctx* c, int li, int tt, bool last, bool fold_prev, float a1, float a2) {
@@ -610,17 +839,23 @@ int launch_single(lbm_ctx* c, int li, int tt, bool last, bool fold_prev, float a
       const int nbb = sweep_blocks(c, nb_rows);
       const int nbi = s.nyl > 2 ? sweep_blocks(c, s.nyl - 2) : 0;
       if (fold_prev) { a.prev_partials = s.partials[qp]; a.prev_count = nbb + nbi; a.prev_sum = s.sums + (tt - 1); }
-      HIPC(hipStreamWaitEvent(s.sc, s.ev_recv[qp], 0));
-      launch_sweep(c, a, s.sc);
+      // edge stream: after the halos of the previous launch arrived and its interior finished
+      hipStream_t es = edge_stream(c, s);
+      HIPC(hipStreamWaitEvent(es, s.ev_recv[qp], 0));
+      if (es != s.sc) HIPC(hipStreamWaitEvent(es, s.ev_int[qp], 0));
+      launch_sweep(c, a, es);
       HIPC(hipGetLastError());
-      HIPC(hipEventRecord(s.ev_bnd[q], s.sc));
+      HIPC(hipEventRecord(s.ev_bnd[q], es));
     }
   }
   if (ex) {
     if ((rc = exchange_halos(c, q, 3, 3))) return rc;
     for (auto& s : c->slabs) {
-      if (s.nyl <= 2) continue;
       HIPC(hipSetDevice(s.dev));
+      // interior stream: after the previous launch's edge rows are in place (ev_bnd of launch li-1)
+      const bool split = split_edge_stream(c, s);
+      if (split) HIPC(hipStreamWaitEvent(s.sc, s.ev_bnd[qp], 0));
+      if (s.nyl <= 2) { if (split) HIPC(hipEventRecord(s.ev_int[q], s.sc)); continue; }
       lbm::SweepArgs a;
       a.src = s.lat[c->cur];
       a.dst = s.lat[c->cur ^ 1];
@@ -636,6 +871,7 @@ int launch_single(lbm_ctx* c, int li, int tt, bool last, bool fold_prev, float a
       a.prev_partials = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
       launch_sweep(c, a, s.sc);
       HIPC(hipGetLastError());
+      if (split) HIPC(hipEventRecord(s.ev_int[q], s.sc));
     }
   }
   c->cur ^= 1;
@@ -683,28 +919,210 @@ int launch_pair(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev, floa
       a.ghost_s = s.ghost_s[qp]; a.ghost_n = s.ghost_n[qp];
       a.blocked_gs = s.blocked_gs; a.blocked_gn = s.blocked_gn;
       a.send_s = s.send_s[q]; a.send_n = s.send_n[q];
-      HIPC(hipStreamWaitEvent(s.sc, s.ev_recv[qp], 0));
-      launch_sweep2(c, a, ntx * a.by_count, s.sc, true);
+      hipStream_t es = edge_stream(c, s);
+      HIPC(hipStreamWaitEvent(es, s.ev_recv[qp], 0));
+      if (es != s.sc) HIPC(hipStreamWaitEvent(es, s.ev_int[qp], 0));
+      launch_sweep2(c, a, ntx * a.by_count, es, true);
       HIPC(hipGetLastError());
-      HIPC(hipEventRecord(s.ev_bnd[q], s.sc));
+      HIPC(hipEventRecord(s.ev_bnd[q], es));
     }
   }
   if (ex) {
     if ((rc = exchange_halos(c, q, 0, lbm::kHaloSlots))) return rc;
     for (auto& s : c->slabs) {
       const int nty = s.nyl / kT2Y;
-      if (nty <= 2) continue;
       HIPC(hipSetDevice(s.dev));
+      const bool split = split_edge_stream(c, s);
+      if (split) HIPC(hipStreamWaitEvent(s.sc, s.ev_bnd[qp], 0));
+      if (nty <= 2) { if (split) HIPC(hipEventRecord(s.ev_int[q], s.sc)); continue; }
       lbm::Sweep2Args a;
       fill(s, a);
       a.by_begin = 1; a.by_count = nty - 2; a.by_stride = 1;
       a.partials1 += 2 * ntx; a.partials2 += 2 * ntx;   // after the two edge tile rows
       launch_sweep2(c, a, ntx * (nty - 2), s.sc, false);
       HIPC(hipGetLastError());
+      if (split) HIPC(hipEventRecord(s.ev_int[q], s.sc));
     }
   }
   c->cur ^= 1;
   return LBM_OK;
+}
+
+}  // namespace
+
+namespace {
+
+// End of a run: reduce across ranks (if there is a communicator), wait, fetch the per-step sums.
+int collect_sums(lbm_ctx* c, int nsteps, float* av_vels, std::chrono::steady_clock::time_point wall0) {
+  if (c->rank_mode && c->nranks > 1 && !c->no_comm) {
+    Slab& s = c->slabs[0];
+    NCCLC(rccl::AllReduce(s.sums, s.sums, (size_t)nsteps, rccl::kFloat64, rccl::kSum, s.comm, s.sc));
+  }
+  std::vector<double> acc(nsteps, 0.0), tmp(nsteps);
+  double gpu_ms = 0.0;
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    HIPC(hipStreamSynchronize(s.sx));
+    HIPC(hipStreamSynchronize(s.se));
+    HIPC(hipStreamSynchronize(s.sc));
+    float ms = 0.f;
+    HIPC(hipEventElapsedTime(&ms, s.ev_t0, s.ev_t1));
+    if (ms > gpu_ms) gpu_ms = ms;
+    if (s.counters) {
+      uint32_t err = 0;
+      HIPC(hipMemcpy(&err, s.counters + 32, sizeof(err), hipMemcpyDeviceToHost));
+      if (err) return fail(LBM_EHIP, "peer-to-peer halo wait timed out (a neighbouring slab stopped)");
+    }
+    if (av_vels) {
+      HIPC(hipMemcpy(tmp.data(), s.sums, sizeof(double) * nsteps, hipMemcpyDeviceToHost));
+      for (int i = 0; i < nsteps; ++i) acc[i] += tmp[i];
+    }
+  }
+  c->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  c->gpu_ms = gpu_ms;
+  if (av_vels)
+    for (int i = 0; i < nsteps; ++i) av_vels[i] = (float)(acc[i] / (double)c->tot_fluid);  // d2q9-bgk.c:1811
+  return LBM_OK;
+}
+
+// Peer-to-peer pointers of a slab for launch group `seq` (see lbm::P2PSync); bumps the completion
+// targets by the number of blocks that will count themselves done on each side.
+lbm::P2PSync p2p_sync(Slab& s, uint32_t seq, int blocks_s, int blocks_n) {
+  lbm::P2PSync y;
+  const size_t f = 4 * s.halo_bytes;
+  y.flag_s = (const uint32_t*)(s.comm_block + f);
+  y.flag_n = (const uint32_t*)(s.comm_block + f + 256);
+  y.rem_flag_s = (uint32_t*)(s.peer_s + f + 256);   // I am the south neighbour's NORTH side
+  y.rem_flag_n = (uint32_t*)(s.peer_n + f);
+  y.cnt_s = s.counters; y.cnt_n = s.counters + 16; y.err = s.counters + 32;
+  s.cnt_s_total += (uint32_t)blocks_s; s.cnt_n_total += (uint32_t)blocks_n;
+  y.cnt_target_s = s.cnt_s_total; y.cnt_target_n = s.cnt_n_total;
+  y.seq = seq;
+  return y;
+}
+inline float* p2p_remote_s(const Slab& s, uint32_t seq) { return (float*)(s.peer_s + (size_t)(2 + (seq & 1)) * s.halo_bytes); }  // its ghost_n
+inline float* p2p_remote_n(const Slab& s, uint32_t seq) { return (float*)(s.peer_n + (size_t)(seq & 1) * s.halo_bytes); }        // its ghost_s
+
+// The step loop with peer-to-peer halos: one stream per slab, no events, no host-side exchange.
+// Two-step launches carry the hand-off themselves (edge tiles first); single steps are bracketed
+// by a wait launch and a push launch.
+int run_p2p(lbm_ctx* c, int nsteps, float* av_vels) {
+  if (!c->p2p_connected) return fail(LBM_EINVAL, "peer-to-peer halos are not connected (lbm_p2p_connect)");
+  const int nx = c->p.nx;
+  const float a1 = c->p.density * c->p.accel / 9.f, a2 = c->p.density * c->p.accel / 36.f;
+  const bool pairs = t2_eligible(c) && nsteps >= 2;
+  const int ntx = nx / kT2X;
+  const int push_grid = cdiv(nx, lbm::kBlock);
+  int rc;
+  for (auto& s : c->slabs)
+    if ((rc = ensure_sums(s, nsteps))) return rc;
+
+  auto push = [&](Slab& s, const float* lat, uint32_t seq, bool do_push) -> int {
+    const int grid = do_push ? push_grid : 1;
+    lbm::P2PSync y = p2p_sync(s, seq, do_push ? grid : 0, do_push ? grid : 0);
+    hipLaunchKernelGGL(lbm::lbm_p2p_push, dim3(grid), dim3(lbm::kBlock), 0, s.sc, lat, s.plane, s.pitch, nx, s.nyl,
+                       p2p_remote_s(s, seq), p2p_remote_n(s, seq), y, do_push ? 1 : 0);
+    HIPC(hipGetLastError());
+    return LBM_OK;
+  };
+
+  // ---- prologue: accelerate phase of the first step, then push the halos of the starting lattice
+  uint32_t seq = ++c->seq;
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    if (s.accel_row >= 0) {
+      hipLaunchKernelGGL(lbm::lbm_accelerate_row, dim3(cdiv(nx, 256)), dim3(256), 0, s.sc,
+                         s.lat[c->cur], s.plane, s.pitch, nx, s.accel_row, s.blocked, a1, a2);
+      HIPC(hipGetLastError());
+    }
+    if ((rc = push(s, s.lat[c->cur], seq, true))) return rc;
+  }
+  const auto wall0 = std::chrono::steady_clock::now();
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    HIPC(hipEventRecord(s.ev_t0, s.sc));
+  }
+
+  int li = 0, tt = 0;
+  if (pairs) {
+    const int npairs = nsteps / 2;
+    for (int j = 0; j < npairs; ++j, ++li, tt += 2) {
+      seq = ++c->seq;
+      const int q = li & 1, qp = q ^ 1;
+      for (auto& s : c->slabs) {
+        HIPC(hipSetDevice(s.dev));
+        const int nty = s.nyl / kT2Y, nbtot = ntx * nty;
+        lbm::Sweep2Args a;
+        a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
+        a.plane = s.plane; a.pitch = s.pitch; a.nx = nx; a.ny = s.nyl;
+        a.blocked = s.blocked; a.omega = c->p.omega;
+        a.accel_row = s.accel_row >= 0 ? s.accel_row : lbm::kNoRow;
+        a.accel_out = (tt + 2 < nsteps) ? 1 : 0;
+        a.a1 = a1; a.a2 = a2;
+        a.partials1 = s.partials[q]; a.partials2 = s.partials[q] + nbtot;
+        a.prev1 = a.prev2 = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
+        if (j > 0) { a.prev1 = s.partials[qp]; a.prev2 = s.partials[qp] + nbtot; a.prev_count = nbtot; a.prev_sum = s.sums + (tt - 2); }
+        a.by_begin = 0; a.by_count = nty; a.by_stride = 1;
+        a.ghost_s = s.ghost_s[(seq - 1) & 1]; a.ghost_n = s.ghost_n[(seq - 1) & 1];
+        a.blocked_gs = s.blocked_gs; a.blocked_gn = s.blocked_gn;
+        a.send_s = p2p_remote_s(s, seq); a.send_n = p2p_remote_n(s, seq);
+        a.sync = p2p_sync(s, seq, ntx, ntx);
+        launch_sweep2_k<lbm::kSweep2P2P>(c, a, nbtot, s.sc);
+        HIPC(hipGetLastError());
+      }
+      c->cur ^= 1;
+    }
+    const int ql = (li - 1) & 1;
+    for (auto& s : c->slabs) {
+      HIPC(hipSetDevice(s.dev));
+      const int nbtot = ntx * (s.nyl / kT2Y);
+      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql], nbtot, s.sums + (tt - 2));
+      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql] + nbtot, nbtot, s.sums + (tt - 1));
+      HIPC(hipGetLastError());
+    }
+  }
+  const int first_single = tt;
+  for (; tt < nsteps; ++tt, ++li) {
+    seq = ++c->seq;
+    const int q = li & 1, qp = q ^ 1;
+    const bool last = (tt == nsteps - 1);
+    const long h3 = 3L * nx;
+    for (auto& s : c->slabs) {
+      HIPC(hipSetDevice(s.dev));
+      if ((rc = push(s, nullptr, seq, false))) return rc;   // wait for the halos of launch seq-1
+      lbm::SweepArgs a;
+      a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
+      a.plane = s.plane; a.pitch = s.pitch; a.nx = nx; a.nyl = s.nyl;
+      a.blocked = s.blocked; a.omega = c->p.omega;
+      a.accel_row = last ? -1 : s.accel_row;
+      a.a1 = a1; a.a2 = a2;
+      a.partials = s.partials[q];
+      const float* gs = s.ghost_s[(seq - 1) & 1] + h3;
+      const float* gn = s.ghost_n[(seq - 1) & 1] + h3;
+      a.south2 = gs; a.south5 = gs + nx; a.south6 = gs + 2 * nx;
+      a.north4 = gn; a.north7 = gn + nx; a.north8 = gn + 2 * nx;
+      a.send_south = a.send_north = nullptr;
+      a.y_begin = 0; a.y_count = s.nyl; a.y_stride = 1;
+      const int nb = sweep_blocks(c, s.nyl);
+      a.prev_partials = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
+      if (tt > first_single) { a.prev_partials = s.partials[qp]; a.prev_count = nb; a.prev_sum = s.sums + (tt - 1); }
+      launch_sweep(c, a, s.sc);
+      HIPC(hipGetLastError());
+      if ((rc = push(s, s.lat[c->cur ^ 1], seq, true))) return rc;   // the new edge rows, packed and pushed
+    }
+    c->cur ^= 1;
+  }
+  const int ql = (li - 1) & 1;
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    if (first_single < nsteps) {
+      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql],
+                         sweep_blocks(c, s.nyl), s.sums + (nsteps - 1));
+      HIPC(hipGetLastError());
+    }
+    HIPC(hipEventRecord(s.ev_t1, s.sc));
+  }
+  return collect_sums(c, nsteps, av_vels, wall0);
 }
 
 }  // namespace
@@ -716,6 +1134,7 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
   const int nx = c->p.nx;
   const float a1 = c->p.density * c->p.accel / 9.f;   // d2q9-bgk.c:230-231
   const float a2 = c->p.density * c->p.accel / 36.f;
+  if (c->exchange == LBM_EXCHANGE_P2P) return run_p2p(c, nsteps, av_vels);
   const bool ex = c->exchange != 0;
   const bool pairs = t2_eligible(c) && nsteps >= 2;
   int rc;
@@ -739,7 +1158,8 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
         hipLaunchKernelGGL(lbm::lbm_pack_halos, dim3(cdiv(nx, 256)), dim3(256), 0, s.sc,
                            s.lat[c->cur], s.plane, s.pitch, nx, s.nyl, s.send_s[1] + 3L * nx, s.send_n[1] + 3L * nx);
       HIPC(hipGetLastError());
-      HIPC(hipEventRecord(s.ev_bnd[1], s.sc));
+      HIPC(hipEventRecord(s.ev_bnd[1], s.sc));   // "edge rows of launch -1 are in place"
+      if (split_edge_stream(c, s)) HIPC(hipEventRecord(s.ev_int[1], s.sc));   // "interior of launch -1 is done"
     }
   }
   if (ex && (rc = pairs ? exchange_halos(c, 1, 0, lbm::kHaloSlots) : exchange_halos(c, 1, 3, 3))) return rc;
@@ -761,6 +1181,7 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
     const int ql = (li - 1) & 1;
     for (auto& s : c->slabs) {  // fold the last pair's partials
       HIPC(hipSetDevice(s.dev));
+      if (ex && split_edge_stream(c, s)) HIPC(hipStreamWaitEvent(s.sc, s.ev_bnd[ql], 0));   // join the edge stream
       const int nbtot = (nx / kT2X) * (s.nyl / kT2Y);
       hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql], nbtot, s.sums + (tt - 2));
       hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql] + nbtot, nbtot, s.sums + (tt - 1));
@@ -775,6 +1196,7 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
   const int ql = (li - 1) & 1;
   for (auto& s : c->slabs) {
     HIPC(hipSetDevice(s.dev));
+    if (ex && split_edge_stream(c, s)) HIPC(hipStreamWaitEvent(s.sc, s.ev_bnd[ql], 0));     // join the edge stream
     if (first_single < nsteps) {
       hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql],
                          single_partial_count(c, s), s.sums + (nsteps - 1));
@@ -783,29 +1205,7 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
     HIPC(hipEventRecord(s.ev_t1, s.sc));
     if (ex) HIPC(hipStreamWaitEvent(s.sc, s.ev_recv[ql], 0));  // drain the last exchange
   }
-  if (c->rank_mode && c->nranks > 1) {
-    Slab& s = c->slabs[0];
-    NCCLC(rccl::AllReduce(s.sums, s.sums, (size_t)nsteps, rccl::kFloat64, rccl::kSum, s.comm, s.sc));
-  }
-  std::vector<double> acc(nsteps, 0.0), tmp(nsteps);
-  double gpu_ms = 0.0;
-  for (auto& s : c->slabs) {
-    HIPC(hipSetDevice(s.dev));
-    HIPC(hipStreamSynchronize(s.sx));
-    HIPC(hipStreamSynchronize(s.sc));
-    float ms = 0.f;
-    HIPC(hipEventElapsedTime(&ms, s.ev_t0, s.ev_t1));
-    if (ms > gpu_ms) gpu_ms = ms;
-    if (av_vels) {
-      HIPC(hipMemcpy(tmp.data(), s.sums, sizeof(double) * nsteps, hipMemcpyDeviceToHost));
-      for (int i = 0; i < nsteps; ++i) acc[i] += tmp[i];
-    }
-  }
-  c->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-  c->gpu_ms = gpu_ms;
-  if (av_vels)
-    for (int i = 0; i < nsteps; ++i) av_vels[i] = (float)(acc[i] / (double)c->tot_fluid);  // d2q9-bgk.c:1811
-  return LBM_OK;
+  return collect_sums(c, nsteps, av_vels, wall0);
 }
 
 extern "C" int lbm_last_run_ms(const lbm_ctx* c, double* gpu_ms, double* wall_ms) {
@@ -853,7 +1253,7 @@ static int derive_all(lbm_ctx* c, float* out4, double* speed_sum, double* mass) 
     hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, part, grid, res);
     hipLaunchKernelGGL(lbm::lbm_fold_double, dim3(1), dim3(lbm::kBlock), 0, s.sc, mpart, grid, res + 1);
     HIPC(hipGetLastError());
-    if (c->rank_mode && c->nranks > 1)
+    if (c->rank_mode && c->nranks > 1 && !c->no_comm)
       NCCLC(rccl::AllReduce(res, res, 2, rccl::kFloat64, rccl::kSum, s.comm, s.sc));
     HIPC(hipStreamSynchronize(s.sc));
     double h[2];

@@ -384,6 +384,64 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep(const SweepArgs a) {
 constexpr int kHaloSlots = 9;
 constexpr int kNoRow = -100;   // "no accelerate row on this slab"
 
+// In-kernel halo hand-off between neighbouring slabs (peer-to-peer mode).  Every launch group has a
+// sequence number seq (the same on every slab).  A launch reads the halos its neighbours pushed
+// with seq-1 (buffer parity (seq-1)&1) and pushes its own new edge rows with seq (parity seq&1)
+// straight into the neighbours' halo buffers, which are uncached device memory mapped on both
+// sides (same process: peer access; other process: hipIpc).  Protocol per edge block:
+//   wait (lane 0 polls, system scope) until my flag from that side >= seq-1, THEN compute and
+//   write remotely, system-scope fence, bump a local completion counter; the block that completes
+//   the side's tile row stores seq to the neighbour's flag.
+// Waiting before writing is what makes two buffers enough: the neighbour's flag seq-1 is only
+// raised after all its edge blocks of launch seq-1 -- the last readers of the buffer this launch
+// overwrites -- have finished.  Every spin is bounded (wall clock); a timeout raises *err.
+struct P2PSync {
+  const uint32_t* flag_s;      // written by the south neighbour: "pushed seq X into your ghost_s"
+  const uint32_t* flag_n;      // written by the north neighbour
+  uint32_t* rem_flag_s;        // the south neighbour's flag_n (I am its north side)
+  uint32_t* rem_flag_n;        // the north neighbour's flag_s
+  uint32_t* cnt_s;             // local completion counters, monotonic over the life of the context
+  uint32_t* cnt_n;
+  uint32_t cnt_target_s, cnt_target_n;   // counter value once the last edge block of this launch arrives
+  uint32_t seq;
+  uint32_t* err;
+};
+
+__device__ __forceinline__ void p2p_wait(const uint32_t* flag, uint32_t want, uint32_t* err) {
+  const long long t0 = wall_clock64();   // 100 MHz
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+    __builtin_amdgcn_s_sleep(8);
+    if (wall_clock64() - t0 > 400000000LL) {   // 4 s: the neighbour is gone
+      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);   // system scope: invalidates this CU's L1 ...
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and the barrier behind us waits for it
+}
+
+// Producer side, in this order (MI355X_MICROARCH.md, inter-workgroup visibility, valid forms):
+// every storing wave drains its stores (p2p_drain), the workgroup's barrier, then ONE lane:
+// system-scope release, drain, count the block done; the block that completes the tile row
+// raises the neighbour's flag.
+__device__ __forceinline__ void p2p_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ void p2p_signal(uint32_t* cnt, uint32_t target, uint32_t* rem_flag, uint32_t seq) {
+  __atomic_thread_fence(__ATOMIC_RELEASE);   // system scope
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint32_t old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (old + 1u == target) {
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(rem_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// kinds of two-step launch
+constexpr int kSweep2Plain = 0;   // tile rows that never look outside the slab / slab alone (periodic wrap)
+constexpr int kSweep2Edge = 1;    // edge tile rows of a slab with neighbours (halos by RCCL or peer copies)
+constexpr int kSweep2P2P = 2;     // whole slab in one launch: edge tile rows first (in-kernel hand-off), then interior
+
 struct Sweep2Args {
   const float* src;
   float* dst;
@@ -406,15 +464,19 @@ struct Sweep2Args {
   // outgoing halos
   const float* ghost_s; const float* ghost_n;
   const uint8_t* blocked_gs; const uint8_t* blocked_gn;
-  float* send_s; float* send_n;
+  float* send_s; float* send_n;   // packed halos out: local send buffers, or (peer-to-peer) the
+                                  // neighbours' own halo buffers, written directly over xGMI
+  // peer-to-peer launches only (kSweep2P2P): in-kernel hand-off, see P2PSync
+  P2PSync sync;
 };
 
 // EDGE = false: the tile rows covered never look outside rows [0, ny) of this slab, or the slab
 // is alone and wraps periodically in y.  EDGE = true: first / last tile row of a slab with
 // neighbours; rows -2, -1, ny, ny+1 come from the halo buffers and the new edge rows are also
 // packed for the neighbours.
-template <int TX, int TY, int MODE, bool EDGE = false>
+template <int TX, int TY, int MODE, int KIND = kSweep2Plain>
 __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
+  constexpr bool EDGE = (KIND == kSweep2Edge);
   static_assert((TX / 4) * TY == kBlock, "phase B: one thread per 4 cells of the tile");
   static_assert(TY >= 2, "rows 0,1 (and ny-2, ny-1) must sit in one tile row");
   constexpr bool FAST = (MODE & kFastMath) != 0;
@@ -440,11 +502,42 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
   // XCD-aware tile order: block ids are dealt round-robin over the 8 XCDs, so give each XCD a
   // contiguous run of tiles -- x-neighbours, which share ring columns, then share an L2.
   const int ntx = a.nx / TX;
-  const int nblk = gridDim.x;
-  int b = blockIdx.x;
-  if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);
-  const int byi = b / ntx, bx = b - byi * ntx;
-  const int by = a.by_begin + byi * a.by_stride;
+  int by, bx;
+  bool edge = EDGE;            // this block's tile row borders a neighbouring slab
+  if constexpr (KIND == kSweep2P2P) {
+    // block ids [0, ntx): tile row 0; [ntx, 2 ntx): last tile row (if there is a second one);
+    // the rest: interior tile rows.  Edge tiles get the lowest ids so they are dispatched first.
+    const int nty = a.ny / TY;
+    const int nedge = (nty >= 2 ? 2 : 1) * ntx;
+    int b = blockIdx.x;
+    if (b < nedge) {
+      edge = true;
+      by = (b < ntx) ? 0 : nty - 1;
+      bx = (b < ntx) ? b : b - ntx;
+    } else {
+      b -= nedge;
+      const int nint = (int)gridDim.x - nedge;
+      if ((nint & 7) == 0) b = (b & 7) * (nint >> 3) + (b >> 3);
+      by = 1 + b / ntx;
+      bx = b - (by - 1) * ntx;
+    }
+    if (edge) {
+      // wait for the halos of launch seq-1 before touching anything remote (see P2PSync)
+      if (threadIdx.x == 0) {
+        const uint32_t want = a.sync.seq - 1u;
+        if (by == 0) p2p_wait(a.sync.flag_s, want, a.sync.err);
+        if (by == nty - 1) p2p_wait(a.sync.flag_n, want, a.sync.err);
+      }
+      __syncthreads();
+    }
+  } else {
+    const int nblk = gridDim.x;
+    int b = blockIdx.x;
+    if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);
+    const int byi = b / ntx;
+    bx = b - byi * ntx;
+    by = a.by_begin + byi * a.by_stride;
+  }
   const int X0 = bx * TX, Y0 = by * TY;
   const long P = a.plane;
   const float* s = a.src;
@@ -463,7 +556,7 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
       const int xw = gx ? gx - 1 : a.nx - 1, xe = (gx + 1 == a.nx) ? 0 : gx + 1;
       int gy = Y0 - 1 + cy;
       const float *c0, *c1, *c3, *s2, *s5, *s6, *n4, *n7, *n8;   // row bases of the nine pulls
-      if constexpr (!EDGE) {
+      if (!edge) {
         gy += (gy < 0) ? a.ny : 0; gy -= (gy >= a.ny) ? a.ny : 0;
         const int ys = gy ? gy - 1 : a.ny - 1, yn = (gy + 1 == a.ny) ? 0 : gy + 1;
         const long rc = (long)gy * a.pitch, rs = (long)ys * a.pitch, rn = (long)yn * a.pitch;
@@ -578,7 +671,7 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
     f4a w; w.x = o[k][0]; w.y = o[k][1]; w.z = o[k][2]; w.w = o[k][3];
     stg<NTS>(reinterpret_cast<f4a*>(d + k * P), w);
   }
-  if constexpr (EDGE) {
+  if (edge) {
     // pack the new edge rows for the neighbours (layout: kHaloSlots comment above)
     auto put = [&](float* buf, int slot, int k) {
       f4a w; w.x = o[k][0]; w.y = o[k][1]; w.z = o[k][2]; w.w = o[k][3];
@@ -590,9 +683,57 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
     if (gy == a.ny - 2) { put(a.send_n, 6, 2); put(a.send_n, 7, 5); put(a.send_n, 8, 6); }
   }
 
-  const float b1 = block_sum<float>(sum1, red_f);
+  const float b1 = block_sum<float>(sum1, red_f);   // (contains a __syncthreads: all remote stores issued)
   const float b2 = block_sum<float>(sum2, red_g);
   if (threadIdx.x == 0) { a.partials1[blockIdx.x] = b1; a.partials2[blockIdx.x] = b2; }
+  if constexpr (KIND == kSweep2P2P) {
+    if (edge) {
+      // every wave's remote stores must have left before the block counts itself done
+      p2p_drain();
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int nty = a.ny / TY;
+        if (by == 0) p2p_signal(a.sync.cnt_s, a.sync.cnt_target_s, a.sync.rem_flag_s, a.sync.seq);
+        if (by == nty - 1) p2p_signal(a.sync.cnt_n, a.sync.cnt_target_n, a.sync.rem_flag_n, a.sync.seq);
+      }
+    }
+  }
+}
+
+// Peer-to-peer mode, outside the fused two-step launch: waits for the neighbours' halos of launch
+// seq-1 (both sides), then -- if lat != nullptr -- packs the nine halo slots of a resident lattice
+// straight into the neighbours' buffers and raises their flags with seq.  One block per 256 columns.
+__global__ __launch_bounds__(kBlock) void lbm_p2p_push(const float* lat, long plane, int pitch, int nx, int nyl,
+                                                       float* rem_s, float* rem_n, P2PSync sync, int do_push) {
+  if (threadIdx.x == 0) {
+    p2p_wait(sync.flag_s, sync.seq - 1u, sync.err);
+    p2p_wait(sync.flag_n, sync.seq - 1u, sync.err);
+  }
+  __syncthreads();
+  if (!do_push) return;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x < nx) {
+    const long r0 = x, r1 = (long)pitch + x;
+    const long t1 = (long)(nyl - 1) * pitch + x, t2 = (long)(nyl - 2) * pitch + x;
+    const int ks[6] = {0, 1, 3, 4, 7, 8}, kn[6] = {0, 1, 3, 2, 5, 6};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      rem_s[(long)i * nx + x] = lat[ks[i] * plane + r0];
+      rem_n[(long)i * nx + x] = lat[kn[i] * plane + t1];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      rem_s[(long)(6 + i) * nx + x] = lat[ks[3 + i] * plane + r1];
+      rem_n[(long)(6 + i) * nx + x] = lat[kn[3 + i] * plane + t2];
+    }
+  }
+  p2p_drain();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // every block serves both neighbours: it counts itself done on both sides
+    p2p_signal(sync.cnt_s, sync.cnt_target_s, sync.rem_flag_s, sync.seq);
+    p2p_signal(sync.cnt_n, sync.cnt_target_n, sync.rem_flag_n, sync.seq);
+  }
 }
 
 // Packs all nine halo slots of a resident lattice (start of a run).  Needs nyl >= 2.

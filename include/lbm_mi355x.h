@@ -60,6 +60,10 @@ typedef struct lbm_ctx lbm_ctx;
 #define LBM_EXCHANGE_AUTO   0  /* 1 slab: none (periodic self-wrap); >1 slabs: RCCL */
 #define LBM_EXCHANGE_COPY   1  /* hipMemcpyAsync between slabs of ONE process (peer copies) */
 #define LBM_EXCHANGE_RCCL   2  /* ncclSend/ncclRecv pairs over xGMI, own stream, overlapped */
+#define LBM_EXCHANGE_P2P    3  /* kernels store their halo rows straight into the neighbour's
+                                  buffers over xGMI and hand off through flags (no host, no
+                                  collective call in the step loop); needs peer access (one
+                                  process) or hipIpc (one process per GPU) */
 
 /* Message of the last failure on this thread ("" if none). */
 const char* lbm_last_error(void);
@@ -93,6 +97,25 @@ int lbm_create(const lbm_param* params, const int* obstacles, const float* cells
 int lbm_rccl_unique_id(void* id128);
 int lbm_create_rank(const lbm_param* params, const int* obstacles, const float* cells,
                     int rank, int nranks, int device, const void* unique_id, lbm_ctx** out);
+
+/*
+ * Same, with the halo transport chosen by the caller (LBM_EXCHANGE_RCCL or LBM_EXCHANGE_P2P;
+ * lbm_create_rank = RCCL unless the environment says LBM_RANK_EXCHANGE=p2p).
+ *   unique_id != NULL: the library forms a RCCL communicator (used for the end-of-run
+ *     reductions, for RCCL halos, and to trade the hipIpc handles of peer-to-peer halos);
+ *     if peer-to-peer set-up fails on ANY rank, all ranks fall back to RCCL halos together.
+ *   unique_id == NULL (peer-to-peer only): no RCCL at all.  The caller trades the 64-byte
+ *     handles itself -- lbm_p2p_handle() on every rank, all-gather by any means,
+ *     lbm_p2p_connect() with all nranks handles in rank order -- before the first lbm_run;
+ *     lbm_run / lbm_av_velocity / lbm_total_density then return this rank's CONTRIBUTION
+ *     (slab sum over the global fluid-cell count), to be added across ranks by the caller.
+ */
+int lbm_create_rank_ex(const lbm_param* params, const int* obstacles, const float* cells,
+                       int rank, int nranks, int device, const void* unique_id, int exchange,
+                       lbm_ctx** out);
+#define LBM_P2P_HANDLE_BYTES 64
+int lbm_p2p_handle(lbm_ctx* ctx, void* handle64);
+int lbm_p2p_connect(lbm_ctx* ctx, const void* handles, int nranks);
 
 /* Rows [row_begin, row_end) of the global lattice held by slab `slab` of this context. */
 int lbm_slab_rows(const lbm_ctx* ctx, int slab, int* row_begin, int* row_end);

@@ -428,3 +428,123 @@ def test_full_size_synthetic_translation_invariance(gpu):
     assert np.array_equal(np.roll(f1, 5, axis=1).view(np.uint32), f2.view(np.uint32))
     assert np.allclose(av1, av2, rtol=2e-6, atol=0)
     assert np.all(np.isfinite(av1)) and np.all(av1 > 0) and np.all(np.diff(av1) > 0)   # flow spins up
+
+
+@pytest.mark.parametrize("deck,nslabs,time_block", [
+    ("128x256", 2, 2), ("128x128", 4, 2), ("128x256", 1, 2), ("128x256", 3, 2), ("1024x1024", 4, 2), ("128x256", 2, 1)])
+def test_peer_to_peer_halos_single_process(gpu, deck, nslabs, time_block):
+    """LBM_EXCHANGE_P2P: kernels store their edge rows straight into the neighbour slab's halo buffers
+    and hand off through flags polled in-kernel -- one launch per pair of steps, no events, no host
+    exchange.  Slabs on one GPU here (the protocol is the same across GPUs; the memory is then a
+    peer mapping).  Several runs in a row exercise the sequence numbering across lbm_run calls; 3
+    slabs of 256 rows do not tile, so they take the single-step form (wait launch, sweep, push launch)."""
+    L = gpu
+    pf, of = deck_paths(deck)
+    p = L.read_params(pf)
+    ob = L.read_obstacles(of, p)
+    splits = (40, 7, 1, 2, 13)
+    with L.Lattice(p, ob) as lat:
+        lat.set_option("time_block", 1)
+        av1 = np.concatenate([lat.run(n) for n in splits])
+        st1 = lat.read_state()
+    if nslabs == 1:
+        os.environ["LBM_FORCE_EXCHANGE"] = "1"
+    try:
+        with L.Lattice(p, ob, nslabs=nslabs, devices=[0] * nslabs, exchange=L.EXCHANGE_P2P) as lat:
+            lat.set_option("time_block", time_block)
+            assert lat.info("exchange") == L.EXCHANGE_P2P
+            av2 = np.concatenate([lat.run(n) for n in splits])
+            st2 = lat.read_state()
+            re2 = lat.reynolds()
+    finally:
+        os.environ.pop("LBM_FORCE_EXCHANGE", None)
+    assert np.array_equal(st1.view(np.uint32), st2.view(np.uint32))
+    assert np.allclose(av1, av2, rtol=2e-6, atol=0)
+    assert np.isfinite(re2)
+
+
+def test_peer_to_peer_halos_rank_context_ring_of_one(gpu):
+    """Rank form with a RCCL communicator (handle all-gather, agreement all-reduce) on a ring of one."""
+    L = gpu
+    pf, of = deck_paths("128x256")
+    p = L.read_params(pf)
+    ob = L.read_obstacles(of, p)
+    with L.Lattice(p, ob) as lat:
+        av1 = lat.run(41)
+        st1 = lat.read_state()
+    os.environ["LBM_FORCE_EXCHANGE"] = "1"
+    try:
+        with L.Lattice(p, ob, rank=0, nranks=1, device=0, unique_id=L.rccl_unique_id(), exchange=L.EXCHANGE_P2P) as lat:
+            assert lat.info("exchange") == L.EXCHANGE_P2P
+            av2 = lat.run(41)
+            st2 = lat.read_state()
+    finally:
+        del os.environ["LBM_FORCE_EXCHANGE"]
+    assert np.array_equal(st1.view(np.uint32), st2.view(np.uint32))
+    assert np.allclose(av1, av2, rtol=2e-6, atol=0)
+
+
+def _p2p_rank_worker(rank, nranks, deck, nsteps_list, conn, outdir):
+    import sys
+    for p_ in (ROOT, os.path.join(ROOT, "oracle")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    import advanced_hpc_lbm_amd as L
+    pf, of = deck
+    p = L.read_params(pf)
+    ob = L.read_obstacles(of, p)
+    # no RCCL (two ranks on one GPU cannot form a communicator): the handles travel through the parent
+    lat = L.Lattice(p, ob, rank=rank, nranks=nranks, device=0, unique_id=None, exchange=L.EXCHANGE_P2P)
+    conn.send(lat.p2p_handle())
+    lat.p2p_connect(conn.recv())
+    av = np.concatenate([lat.run(n) for n in nsteps_list])
+    np.save(os.path.join(outdir, f"av_{rank}.npy"), av)
+    np.save(os.path.join(outdir, f"state_{rank}.npy"), lat.read_state())
+    conn.send("done")
+    conn.recv()          # keep the halo block mapped until every rank has finished
+    lat.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_peer_to_peer_halos_between_processes(gpu, tmp_path, nranks):
+    """One process per slab, halo blocks mapped across processes with hipIpc handles, in-kernel
+    hand-off between kernels of DIFFERENT processes (here sharing one GPU).  No RCCL involved: the
+    per-rank av_vels contributions are added by the caller."""
+    import multiprocessing as mp
+    L = gpu
+    deck = "128x256" if nranks == 2 else "1024x1024"    # 3 ranks of 1024 rows do not tile: single-step form
+    pf, of = deck_paths(deck)
+    p = L.read_params(pf)
+    ob = L.read_obstacles(of, p)
+    splits = [30, 5]
+    with L.Lattice(p, ob) as lat:
+        av1 = np.concatenate([lat.run(n) for n in splits])
+        st1 = lat.read_state()
+    ctx = mp.get_context("spawn")
+    pipes = [ctx.Pipe() for _ in range(nranks)]
+    procs = [ctx.Process(target=_p2p_rank_worker, args=(r, nranks, (pf, of), splits, pipes[r][1], str(tmp_path)))
+             for r in range(nranks)]
+    for pr in procs:
+        pr.start()
+    try:
+        handles = []
+        for r in range(nranks):
+            assert pipes[r][0].poll(120), f"rank {r} did not come up"
+            handles.append(pipes[r][0].recv())
+        for r in range(nranks):
+            pipes[r][0].send(handles)
+        for r in range(nranks):
+            assert pipes[r][0].poll(120), f"rank {r} did not finish"
+            assert pipes[r][0].recv() == "done"
+        for r in range(nranks):
+            pipes[r][0].send("bye")
+    finally:
+        for pr in procs:
+            pr.join(60)
+            if pr.is_alive():
+                pr.kill()
+    assert all(pr.exitcode == 0 for pr in procs)
+    av2 = sum(np.load(tmp_path / f"av_{r}.npy").astype(np.float64) for r in range(nranks))
+    st2 = np.concatenate([np.load(tmp_path / f"state_{r}.npy") for r in range(nranks)], axis=0)
+    assert np.array_equal(st1.view(np.uint32), st2.view(np.uint32))
+    assert np.allclose(av1, av2, rtol=2e-6, atol=0)
