@@ -426,15 +426,21 @@ __device__ __forceinline__ void p2p_wait(const uint32_t* flag, uint32_t want, ui
 // raises the neighbour's flag.
 __device__ __forceinline__ void p2p_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// The halo stores themselves are system-scope write-through stores (p2p_store) into uncached
+// memory, so no L2 write-back fence is needed here -- a system-scope release would write back the
+// whole XCD L2, which is full of freshly written lattice lines (measured: +11 % on 8192^2).
 __device__ __forceinline__ void p2p_signal(uint32_t* cnt, uint32_t target, uint32_t* rem_flag, uint32_t seq) {
-  __atomic_thread_fence(__ATOMIC_RELEASE);   // system scope
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const uint32_t old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (old + 1u == target) {
-    __atomic_thread_fence(__ATOMIC_SEQ_CST);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the returned add orders behind every block's drain
     __hip_atomic_store(rem_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+// One float into a neighbour's halo block: system scope (sc0 sc1), written through, never left in L2.
+__device__ __forceinline__ void p2p_store(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // kinds of two-step launch
@@ -469,6 +475,75 @@ struct Sweep2Args {
   // peer-to-peer launches only (kSweep2P2P): in-kernel hand-off, see P2PSync
   P2PSync sync;
 };
+
+// Phase A gather of lbm_sweep2: the nine pulled values, blocked flag and region coordinates of the
+// cells this thread computes for step t+1.  E = the tile row borders a neighbouring slab.
+template <int TX, int TY, bool NTL, bool E, int NA>
+__device__ __forceinline__ void sweep2_gather(const Sweep2Args& a, int X0, int Y0, float (&q)[NA][9], bool (&blk)[NA],
+                                              int (&cxs)[NA], int (&cys)[NA]) {
+  constexpr int IW = TX + 2, IH = TY + 2;
+  const long P = a.plane;
+  const float* s = a.src;
+#pragma unroll
+  for (int m = 0; m < NA; ++m) {
+    const int idx = threadIdx.x + m * kBlock;
+    const int cy = idx / IW, cx = idx - cy * IW;
+    cxs[m] = cx; cys[m] = cy;
+    if (idx < IW * IH) {
+      int gx = X0 - 1 + cx; gx += (gx < 0) ? a.nx : 0; gx -= (gx >= a.nx) ? a.nx : 0;
+      const int xw = gx ? gx - 1 : a.nx - 1, xe = (gx + 1 == a.nx) ? 0 : gx + 1;
+      int gy = Y0 - 1 + cy;
+      const float *c0, *c1, *c3, *s2, *s5, *s6, *n4, *n7, *n8;   // row bases of the nine pulls
+      if constexpr (!E) {
+        gy += (gy < 0) ? a.ny : 0; gy -= (gy >= a.ny) ? a.ny : 0;
+        const int ys = gy ? gy - 1 : a.ny - 1, yn = (gy + 1 == a.ny) ? 0 : gy + 1;
+        const long rc = (long)gy * a.pitch, rs = (long)ys * a.pitch, rn = (long)yn * a.pitch;
+        c0 = s + rc; c1 = s + P + rc; c3 = s + 3 * P + rc;
+        s2 = s + 2 * P + rs; s5 = s + 5 * P + rs; s6 = s + 6 * P + rs;
+        n4 = s + 4 * P + rn; n7 = s + 7 * P + rn; n8 = s + 8 * P + rn;
+        blk[m] = a.blocked[rc + gx] != 0;
+      } else {
+        // gy in [-1, ny]; its south row in [-2, ny-1], its north row in [0, ny+1]
+        const int nxl = a.nx;
+        const long rc = (long)gy * a.pitch;
+        if (gy < 0) {            // ring row -1: centre planes from the southern halo
+          c0 = a.ghost_s; c1 = a.ghost_s + nxl; c3 = a.ghost_s + 2 * nxl;
+          blk[m] = a.blocked_gs[gx] != 0;
+        } else if (gy >= a.ny) { // ring row ny
+          c0 = a.ghost_n; c1 = a.ghost_n + nxl; c3 = a.ghost_n + 2 * nxl;
+          blk[m] = a.blocked_gn[gx] != 0;
+        } else {
+          c0 = s + rc; c1 = s + P + rc; c3 = s + 3 * P + rc;
+          blk[m] = a.blocked[rc + gx] != 0;
+        }
+        if (gy <= 0) {           // south row is -2 (gy = -1) or -1 (gy = 0)
+          const float* g = a.ghost_s + (gy < 0 ? 6 : 3) * nxl;
+          s2 = g; s5 = g + nxl; s6 = g + 2 * nxl;
+        } else {
+          const long rs = rc - a.pitch;
+          s2 = s + 2 * P + rs; s5 = s + 5 * P + rs; s6 = s + 6 * P + rs;
+        }
+        if (gy >= a.ny - 1) {    // north row is ny (gy = ny-1) or ny+1 (gy = ny)
+          const float* g = a.ghost_n + (gy >= a.ny ? 6 : 3) * nxl;
+          n4 = g; n7 = g + nxl; n8 = g + 2 * nxl;
+        } else {
+          const long rn = rc + a.pitch;
+          n4 = s + 4 * P + rn; n7 = s + 7 * P + rn; n8 = s + 8 * P + rn;
+        }
+      }
+      q[m][0] = ldg<NTL>(c0 + gx);
+      q[m][1] = ldg<NTL>(c1 + xw);
+      q[m][2] = ldg<NTL>(s2 + gx);
+      q[m][3] = ldg<NTL>(c3 + xe);
+      q[m][4] = ldg<NTL>(n4 + gx);
+      q[m][5] = ldg<NTL>(s5 + xw);
+      q[m][6] = ldg<NTL>(s6 + xe);
+      q[m][7] = ldg<NTL>(n7 + xe);
+      q[m][8] = ldg<NTL>(n8 + xw);
+      cys[m] = cy | (gy == a.accel_row ? 0x10000 : 0);
+    }
+  }
+}
 
 // EDGE = false: the tile rows covered never look outside rows [0, ny) of this slab, or the slab
 // is alone and wraps periodically in y.  EDGE = true: first / last tile row of a slab with
@@ -540,71 +615,16 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
   }
   const int X0 = bx * TX, Y0 = by * TY;
   const long P = a.plane;
-  const float* s = a.src;
 
   // ---- phase A: step t+1 on the (TX+2) x (TY+2) region -> LDS
   float q[NA][9];
   bool blk[NA];
   int cxs[NA], cys[NA];
-#pragma unroll
-  for (int m = 0; m < NA; ++m) {
-    const int idx = threadIdx.x + m * kBlock;
-    const int cy = idx / IW, cx = idx - cy * IW;
-    cxs[m] = cx; cys[m] = cy;
-    if (idx < IW * IH) {
-      int gx = X0 - 1 + cx; gx += (gx < 0) ? a.nx : 0; gx -= (gx >= a.nx) ? a.nx : 0;
-      const int xw = gx ? gx - 1 : a.nx - 1, xe = (gx + 1 == a.nx) ? 0 : gx + 1;
-      int gy = Y0 - 1 + cy;
-      const float *c0, *c1, *c3, *s2, *s5, *s6, *n4, *n7, *n8;   // row bases of the nine pulls
-      if (!edge) {
-        gy += (gy < 0) ? a.ny : 0; gy -= (gy >= a.ny) ? a.ny : 0;
-        const int ys = gy ? gy - 1 : a.ny - 1, yn = (gy + 1 == a.ny) ? 0 : gy + 1;
-        const long rc = (long)gy * a.pitch, rs = (long)ys * a.pitch, rn = (long)yn * a.pitch;
-        c0 = s + rc; c1 = s + P + rc; c3 = s + 3 * P + rc;
-        s2 = s + 2 * P + rs; s5 = s + 5 * P + rs; s6 = s + 6 * P + rs;
-        n4 = s + 4 * P + rn; n7 = s + 7 * P + rn; n8 = s + 8 * P + rn;
-        blk[m] = a.blocked[rc + gx] != 0;
-      } else {
-        // gy in [-1, ny]; its south row in [-2, ny-1], its north row in [0, ny+1]
-        const int nxl = a.nx;
-        const long rc = (long)gy * a.pitch;
-        if (gy < 0) {            // ring row -1: centre planes from the southern halo
-          c0 = a.ghost_s; c1 = a.ghost_s + nxl; c3 = a.ghost_s + 2 * nxl;
-          blk[m] = a.blocked_gs[gx] != 0;
-        } else if (gy >= a.ny) { // ring row ny
-          c0 = a.ghost_n; c1 = a.ghost_n + nxl; c3 = a.ghost_n + 2 * nxl;
-          blk[m] = a.blocked_gn[gx] != 0;
-        } else {
-          c0 = s + rc; c1 = s + P + rc; c3 = s + 3 * P + rc;
-          blk[m] = a.blocked[rc + gx] != 0;
-        }
-        if (gy <= 0) {           // south row is -2 (gy = -1) or -1 (gy = 0)
-          const float* g = a.ghost_s + (gy < 0 ? 6 : 3) * nxl;
-          s2 = g; s5 = g + nxl; s6 = g + 2 * nxl;
-        } else {
-          const long rs = rc - a.pitch;
-          s2 = s + 2 * P + rs; s5 = s + 5 * P + rs; s6 = s + 6 * P + rs;
-        }
-        if (gy >= a.ny - 1) {    // north row is ny (gy = ny-1) or ny+1 (gy = ny)
-          const float* g = a.ghost_n + (gy >= a.ny ? 6 : 3) * nxl;
-          n4 = g; n7 = g + nxl; n8 = g + 2 * nxl;
-        } else {
-          const long rn = rc + a.pitch;
-          n4 = s + 4 * P + rn; n7 = s + 7 * P + rn; n8 = s + 8 * P + rn;
-        }
-      }
-      q[m][0] = ldg<NTL>(c0 + gx);
-      q[m][1] = ldg<NTL>(c1 + xw);
-      q[m][2] = ldg<NTL>(s2 + gx);
-      q[m][3] = ldg<NTL>(c3 + xe);
-      q[m][4] = ldg<NTL>(n4 + gx);
-      q[m][5] = ldg<NTL>(s5 + xw);
-      q[m][6] = ldg<NTL>(s6 + xe);
-      q[m][7] = ldg<NTL>(n7 + xe);
-      q[m][8] = ldg<NTL>(n8 + xw);
-      cys[m] = cy | (gy == a.accel_row ? 0x10000 : 0);
-    }
-  }
+  // The gather is instantiated twice with the edge decision as a compile-time constant, chosen
+  // once per block: with a run-time test inside the cell loop the loads of different cells are
+  // separated by branches and no longer issue back to back (8192^2: 502 -> 592 us per step).
+  if (edge) sweep2_gather<TX, TY, NTL, true, NA>(a, X0, Y0, q, blk, cxs, cys);
+  else sweep2_gather<TX, TY, NTL, false, NA>(a, X0, Y0, q, blk, cxs, cys);
   float sum1 = 0.f;
 #pragma unroll
   for (int m = 0; m < NA; ++m) {
@@ -674,8 +694,13 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
   if (edge) {
     // pack the new edge rows for the neighbours (layout: kHaloSlots comment above)
     auto put = [&](float* buf, int slot, int k) {
-      f4a w; w.x = o[k][0]; w.y = o[k][1]; w.z = o[k][2]; w.w = o[k][3];
-      *reinterpret_cast<f4a*>(buf + (long)slot * a.nx + X0 + x) = w;
+      float* dstp = buf + (long)slot * a.nx + X0 + x;
+      if constexpr (KIND == kSweep2P2P) {
+        p2p_store(dstp, o[k][0]); p2p_store(dstp + 1, o[k][1]); p2p_store(dstp + 2, o[k][2]); p2p_store(dstp + 3, o[k][3]);
+      } else {
+        f4a w; w.x = o[k][0]; w.y = o[k][1]; w.z = o[k][2]; w.w = o[k][3];
+        *reinterpret_cast<f4a*>(dstp) = w;
+      }
     };
     if (gy == 0) { put(a.send_s, 0, 0); put(a.send_s, 1, 1); put(a.send_s, 2, 3); put(a.send_s, 3, 4); put(a.send_s, 4, 7); put(a.send_s, 5, 8); }
     if (gy == 1) { put(a.send_s, 6, 4); put(a.send_s, 7, 7); put(a.send_s, 8, 8); }
@@ -718,13 +743,13 @@ __global__ __launch_bounds__(kBlock) void lbm_p2p_push(const float* lat, long pl
     const int ks[6] = {0, 1, 3, 4, 7, 8}, kn[6] = {0, 1, 3, 2, 5, 6};
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      rem_s[(long)i * nx + x] = lat[ks[i] * plane + r0];
-      rem_n[(long)i * nx + x] = lat[kn[i] * plane + t1];
+      p2p_store(rem_s + (long)i * nx + x, lat[ks[i] * plane + r0]);
+      p2p_store(rem_n + (long)i * nx + x, lat[kn[i] * plane + t1]);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      rem_s[(long)(6 + i) * nx + x] = lat[ks[3 + i] * plane + r1];
-      rem_n[(long)(6 + i) * nx + x] = lat[kn[3 + i] * plane + t2];
+      p2p_store(rem_s + (long)(6 + i) * nx + x, lat[ks[3 + i] * plane + r1]);
+      p2p_store(rem_n + (long)(6 + i) * nx + x, lat[kn[3 + i] * plane + t2]);
     }
   }
   p2p_drain();
