@@ -37,6 +37,7 @@ import torch.distributed as dist  # noqa: E402
 
 import advanced_hpc_lbm_amd as L  # noqa: E402
 
+MULTI = False            # set in main(): more than one rank, or --rehearse-multi on one GPU
 BYTES_PER_LUP = 72.0     # 9 float32 reads + 9 float32 writes
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -71,19 +72,80 @@ def make_workload(name: str):
     return p, ob, data
 
 
-def measure(name, world, rank, local_rank, uid, steps, warmup):
+def new_unique_id(world, rank):
+    """A fresh ncclUniqueId from rank 0, broadcast to every rank (one per lattice = one per communicator)."""
+    if not MULTI:
+        return None
+    buf = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    if rank == 0:
+        buf.copy_(torch.frombuffer(bytearray(L.rccl_unique_id()), dtype=torch.uint8))
+    dist.broadcast(buf, src=0)
+    return bytes(buf.cpu().numpy().tobytes())
+
+
+def make_lattice(p, ob, world, rank, local_rank, exchange):
+    if not MULTI:
+        return L.Lattice(p, ob, nslabs=1, devices=[local_rank])
+    return L.Lattice(p, ob, rank=rank, nranks=world, device=local_rank,
+                     unique_id=new_unique_id(world, rank), exchange=exchange)
+
+
+def all_ranks_agree(ok: bool, world) -> bool:
+    t = torch.tensor([0 if ok else 1], dtype=torch.int32, device="cuda")
+    dist.all_reduce(t)
+    return int(t.item()) == 0
+
+
+def choose_exchange(p, ob, world, rank, local_rank):
+    """N > 1: peer-to-peer halos (kernels store into the neighbour's halo block over xGMI, in-kernel
+    flags) if -- on THIS machine, now -- a short run is bit-identical to the same run with RCCL
+    send/recv halos on every rank; otherwise RCCL.  Returns (mode, note)."""
+    if not MULTI:
+        return L.EXCHANGE_AUTO, "none (periodic self-wrap)"
+    if os.environ.get("LBM_BENCH_EXCHANGE", "") == "rccl":
+        return L.EXCHANGE_RCCL, "RCCL send/recv (forced by LBM_BENCH_EXCHANGE)"
+    results, note = {}, ""
+    for mode in (L.EXCHANGE_RCCL, L.EXCHANGE_P2P):
+        ok, st, av = True, None, None
+        try:
+            lat = make_lattice(p, ob, world, rank, local_rank, mode)
+            if mode == L.EXCHANGE_P2P and int(lat.info("exchange")) != L.EXCHANGE_P2P:
+                ok = False          # the library itself fell back (no peer mapping on some rank)
+            if ok:
+                av = np.concatenate([lat.run(6), lat.run(3)])   # pairs, and an odd run: trailing single step
+                st = lat.read_state()
+        except L.LbmError as e:
+            ok, note = False, str(e)
+        ok = all_ranks_agree(ok, world)
+        dist.barrier()
+        try:
+            lat.close()
+        except Exception:
+            pass
+        if not ok:
+            if mode == L.EXCHANGE_RCCL:
+                raise SystemExit(f"RCCL halo exchange failed: {note}")
+            return L.EXCHANGE_RCCL, "RCCL send/recv (peer-to-peer self-check could not run: %s)" % (note or "no peer mapping")
+        results[mode] = (st, av)
+    same = np.array_equal(results[L.EXCHANGE_RCCL][0].view(np.uint32), results[L.EXCHANGE_P2P][0].view(np.uint32)) and \
+        np.array_equal(results[L.EXCHANGE_RCCL][1].view(np.uint32), results[L.EXCHANGE_P2P][1].view(np.uint32))
+    if all_ranks_agree(same, world):
+        return L.EXCHANGE_P2P, ("peer-to-peer: edge tiles store 9*nx floats per direction per PAIR of steps straight into the "
+                                "neighbour's halo block over xGMI, in-kernel flags (self-check at start-up: bit-identical to RCCL send/recv)")
+    return L.EXCHANGE_RCCL, "RCCL send/recv (peer-to-peer self-check MISMATCHED -- not used)"
+
+
+def measure(name, world, rank, local_rank, steps, warmup):
     """Creates the resident lattice, warms up, times exactly `steps` steps."""
     p, ob, data = make_workload(name)
-    if world > 1:
-        lat = L.Lattice(p, ob, rank=rank, nranks=world, device=local_rank, unique_id=uid)
-    else:
-        lat = L.Lattice(p, ob, nslabs=1, devices=[local_rank])
+    exchange, halo_note = choose_exchange(p, ob, world, rank, local_rank)
+    lat = make_lattice(p, ob, world, rank, local_rank, exchange)
     r0, r1 = lat.slab_rows(0)
     if warmup > 0:
         lat.run(warmup)
 
     def fence():
-        if world > 1:
+        if MULTI:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -93,7 +155,7 @@ def measure(name, world, rank, local_rank, uid, steps, warmup):
     fence()
     dt = time.perf_counter() - t0
     gpu_ms, _ = lat.last_run_ms()
-    if world > 1:
+    if MULTI:
         t = torch.tensor([dt, gpu_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, gpu_ms = t[0].item(), t[1].item()
@@ -117,6 +179,7 @@ def measure(name, world, rank, local_rank, uid, steps, warmup):
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "launch_us": round(launch_s * 1e6, 3)},
         "data": data, "params": p, "blocked": int(ob.sum()), "av_last": float(av[-1]), "finite": bool(np.isfinite(av).all()),
+        "halo": halo_note,
     }
 
 
@@ -173,6 +236,12 @@ def cpu_baseline(sample_steps: int):
 
 
 def main():
+    # stdout carries exactly ONE line, the result: RCCL prints a version banner to fd 1 when a
+    # communicator is created, so everything else that writes to fd 1 is sent to stderr
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+    result_out = os.fdopen(result_fd, "w")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000, help="timed steps of the headline workload")
@@ -181,6 +250,9 @@ def main():
     ap.add_argument("--also", default="8192x8192", help="second workload reported under 'also' ('' to skip)")
     ap.add_argument("--also-steps", type=int, default=300)
     ap.add_argument("--cpu-sample-steps", type=int, default=1000, help="0 = skip the CPU baseline")
+    ap.add_argument("--rehearse-multi", action="store_true",
+                    help="one GPU only: run the N>1 code path (RCCL communicator, halo self-check, peer-to-peer "
+                         "halos) on a ring of one rank; not a benchmark configuration")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,26 +265,21 @@ def main():
     if not torch.cuda.is_available() or L.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    uid = None
-    if world > 1:
+    global MULTI
+    MULTI = world > 1 or args.rehearse_multi
+    if MULTI:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:   # rehearsal of the multi-rank code path on one GPU: a ring of one rank
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ["LBM_FORCE_EXCHANGE"] = "1"
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        buf = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            buf.copy_(torch.frombuffer(bytearray(L.rccl_unique_id()), dtype=torch.uint8))
-        dist.broadcast(buf, src=0)
-        uid = bytes(buf.cpu().numpy().tobytes())
 
-    head = measure(args.workload, world, rank, local_rank, uid, args.steps, args.warmup)
+    head = measure(args.workload, world, rank, local_rank, args.steps, args.warmup)
     also = None
     if args.also and args.also != args.workload:
-        if world > 1:  # a second communicator for the second lattice
-            buf = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                buf.copy_(torch.frombuffer(bytearray(L.rccl_unique_id()), dtype=torch.uint8))
-            dist.broadcast(buf, src=0)
-            uid = bytes(buf.cpu().numpy().tobytes())
-        also = measure(args.also, world, rank, local_rank, uid, args.also_steps, min(args.warmup, 20))
+        also = measure(args.also, world, rank, local_rank, args.also_steps, min(args.warmup, 20))
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample_steps > 0:
@@ -235,8 +302,8 @@ def main():
             "data": head["data"],
             "config": {"workload": f"d2q9-bgk {args.workload}, {head['blocked']} blocked cells, "
                                    f"density {p.density:g} accel {p.accel:g} omega {p.omega:g}",
-                       "nx": p.nx, "ny": p.ny, "decomposition": f"{world} row slab(s), one per GPU",
-                       "halo": "none (periodic self-wrap)" if world == 1 else "RCCL send/recv, 3*nx floats per direction per step"},
+                       "nx": p.nx, "ny": p.ny, "decomposition": f"{world} row slab(s), one per GPU" + (" [REHEARSAL of the multi-rank path on a ring of one]" if MULTI and world == 1 else ""),
+                       "halo": head["halo"]},
             "roofline": head["roofline"],
             "cpu_baseline": cpu,
             "hbm_frac_of_peak_whole_job": round(head["mlups"] * BYTES_PER_LUP / 1e3 / (HBM_PEAK_GBS * world), 4),
@@ -246,9 +313,11 @@ def main():
             line["also"] = {args.also: {
                 "value": round(also["mlups"], 1), "unit": "MLUPS", "steps": args.also_steps,
                 "ms_per_step": round(also["ms_per_step"], 6), "roofline": also["roofline"], "data": also["data"],
+                "halo": also["halo"],
                 "hbm_frac_of_peak_whole_job": round(also["mlups"] * BYTES_PER_LUP / 1e3 / (HBM_PEAK_GBS * world), 4)}}
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        result_out.write(json.dumps(line) + "\n")
+        result_out.flush()
+    if MULTI:
         dist.barrier()
         dist.destroy_process_group()
 
