@@ -16,7 +16,7 @@
 **
 ** Optional environment (the two-argument form stays unchanged):
 **   LBM_NGPUS=n        row-partition the lattice over n GPUs (default 1)
-**   LBM_EXCHANGE=rccl|copy   halo transport between slabs (default rccl)
+**   LBM_EXCHANGE=rccl|p2p|copy   halo transport between slabs (default rccl)
 **   LBM_SKIP_FINAL_STATE=1   do not write final_state.dat (huge synthetic lattices)
 */
 #include <stdio.h>
@@ -138,6 +138,7 @@ int main(int argc, char* argv[])
   int ngpus = (e = getenv("LBM_NGPUS")) ? atoi(e) : 1;
   int exchange = LBM_EXCHANGE_AUTO;
   if ((e = getenv("LBM_EXCHANGE")) && !strcmp(e, "copy")) exchange = LBM_EXCHANGE_COPY;
+  if ((e = getenv("LBM_EXCHANGE")) && !strcmp(e, "p2p")) exchange = LBM_EXCHANGE_P2P;
   const int skip_final = (e = getenv("LBM_SKIP_FINAL_STATE")) && atoi(e);
   if (ngpus < 1) die("LBM_NGPUS must be >= 1", __LINE__, __FILE__);
 
