@@ -361,9 +361,9 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep(const SweepArgs a) {
 // updates: 36 B written + 36 B x (TX+2)(TY+2)/(TX TY) read (1.16x for 64 x 16)
 // instead of 144 B, so the sweep runs above the single-step 72 B/LUP roofline.
 //
-// Each LDS plane is stored shifted by (4 - s_k) % 4 columns, s_k = the column
-// offset phase B pulls plane k with (1 for planes 0,2,4; 0 for 1,5,8; 2 for
-// 3,6,7), so that every phase-B read is one aligned ds_read_b128 per plane.
+// Each value is stored in LDS at the coordinates of the tile cell that will pull it (plane k of a
+// region cell P belongs to P + c_k), so LDS holds exactly TX x TY values per plane and every
+// phase-B read is one aligned ds_read_b128 per plane.
 // Per-cell arithmetic is collide_cell / accelerate_cell, exactly as in
 // lbm_sweep: the accelerate phase of step t+2 is applied to the step-t+1 values
 // of row ny-2 as they go into LDS (ring cells included), that of step t+3 to the
@@ -476,6 +476,26 @@ struct Sweep2Args {
   P2PSync sync;
 };
 
+// Order of the tiles inside one XCD's contiguous run: G tile rows at a time, column by column.
+// G > 1 would let vertically adjacent tiles (which share two ring rows of TX cells) run back to
+// back and find those rows in the XCD's L2 -- measured, it loses more in DRAM locality than it
+// saves in re-reads (8192^2, 64x16 tiles: G = 1 508 us, G = 2 513 us, G = 4 590 us per step),
+// so tiles run row-major.
+constexpr int kTileGroup = 1;
+template <int G>
+__device__ __forceinline__ void tile_order(int idx, int ntx, int nrows, int& row, int& col) {
+  const int full = (nrows / G) * G * ntx;       // tiles in complete groups of G rows
+  if (idx < full) {
+    const int g = idx / (G * ntx), rem = idx - g * (G * ntx);
+    col = rem / G;
+    row = g * G + (rem - col * G);
+  } else {                                     // the last, incomplete group: row-major
+    const int rem = idx - full;
+    row = (nrows / G) * G + rem / ntx;
+    col = rem - (rem / ntx) * ntx;
+  }
+}
+
 // Phase A gather of lbm_sweep2: the nine pulled values, blocked flag and region coordinates of the
 // cells this thread computes for step t+1.  E = the tile row borders a neighbouring slab.
 template <int TX, int TY, bool NTL, bool E, int NA>
@@ -557,9 +577,13 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
   constexpr bool FAST = (MODE & kFastMath) != 0;
   constexpr bool NTL = (MODE & kNtLoad) != 0, NTS = (MODE & kNtStore) != 0;
   constexpr int IW = TX + 2, IH = TY + 2;          // step-t+1 region: tile + ring
-  constexpr int LW = (IW + 3 + 3) / 4 * 4;         // LDS row stride (floats), room for the shift
   constexpr int NA = (IW * IH + kBlock - 1) / kBlock;
-  __shared__ __attribute__((aligned(16))) float lds[9][IH][LW];
+  // LDS holds, per plane k, exactly the TX x TY values phase B will pull: the value f_k of region
+  // cell P is wanted by the tile cell P + c_k only, so it is stored at THAT cell's coordinates (and
+  // dropped if P + c_k falls outside the tile -- most components of the ring cells).  36 KB for a
+  // 64 x 16 tile -> 4 blocks per CU, and every phase-B pull is an aligned ds_read_b128 at the
+  // thread's own coordinates.
+  __shared__ __attribute__((aligned(16))) float lds[9][TY][TX];
   __shared__ float red_f[kBlock / 64];
   __shared__ float red_g[kBlock / 64];
   __shared__ double red_d[kBlock / 64];
@@ -593,8 +617,9 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
       b -= nedge;
       const int nint = (int)gridDim.x - nedge;
       if ((nint & 7) == 0) b = (b & 7) * (nint >> 3) + (b >> 3);
-      by = 1 + b / ntx;
-      bx = b - (by - 1) * ntx;
+      int byi;
+      tile_order<kTileGroup>(b, ntx, nty - 2, byi, bx);
+      by = 1 + byi;
     }
     if (edge) {
       // wait for the halos of launch seq-1 before touching anything remote (see P2PSync)
@@ -609,8 +634,8 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
     const int nblk = gridDim.x;
     int b = blockIdx.x;
     if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);
-    const int byi = b / ntx;
-    bx = b - byi * ntx;
+    int byi;
+    tile_order<kTileGroup>(b, ntx, a.by_count, byi, bx);
     by = a.by_begin + byi * a.by_stride;
   }
   const int X0 = bx * TX, Y0 = by * TY;
@@ -635,15 +660,19 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
       if (cys[m] & 0x10000) accelerate_cell(q[m], blk[m], a.a1, a.a2);
       const bool own = (cx >= 1) && (cx <= TX) && (cy >= 1) && (cy <= TY);
       sum1 += own ? sp : 0.f;
-      lds[0][cy][cx + 3] = q[m][0];
-      lds[1][cy][cx + 0] = q[m][1];
-      lds[2][cy][cx + 3] = q[m][2];
-      lds[3][cy][cx + 2] = q[m][3];
-      lds[4][cy][cx + 3] = q[m][4];
-      lds[5][cy][cx + 0] = q[m][5];
-      lds[6][cy][cx + 2] = q[m][6];
-      lds[7][cy][cx + 2] = q[m][7];
-      lds[8][cy][cx + 0] = q[m][8];
+      // tile coordinates of this region cell, and which neighbours exist inside the tile
+      const int x0 = cx - 1, y0 = cy - 1;
+      const bool xc = (x0 >= 0) && (x0 < TX), xe = (x0 + 1 >= 0) && (x0 + 1 < TX), xw = (x0 - 1 >= 0) && (x0 - 1 < TX);
+      const bool yc = (y0 >= 0) && (y0 < TY), yn = (y0 + 1 >= 0) && (y0 + 1 < TY), ys = (y0 - 1 >= 0) && (y0 - 1 < TY);
+      if (xc && yc) lds[0][y0][x0] = q[m][0];
+      if (xe && yc) lds[1][y0][x0 + 1] = q[m][1];          // 1 = E: wanted by the cell to the east
+      if (xc && yn) lds[2][y0 + 1][x0] = q[m][2];          // 2 = N
+      if (xw && yc) lds[3][y0][x0 - 1] = q[m][3];          // 3 = W
+      if (xc && ys) lds[4][y0 - 1][x0] = q[m][4];          // 4 = S
+      if (xe && yn) lds[5][y0 + 1][x0 + 1] = q[m][5];      // 5 = NE
+      if (xw && yn) lds[6][y0 + 1][x0 - 1] = q[m][6];      // 6 = NW
+      if (xw && ys) lds[7][y0 - 1][x0 - 1] = q[m][7];      // 7 = SW
+      if (xe && ys) lds[8][y0 - 1][x0 + 1] = q[m][8];      // 8 = SE
     }
   }
   __syncthreads();
@@ -655,17 +684,15 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
   const long rc = (long)gy * a.pitch + X0 + x;
   float o[9][4];
   {
-    // intermediate column of tile cell x is x+1; plane k is pulled at column x+1 + (-1|0|+1)
-    // and stored shifted, so every row below starts at a 16-byte boundary: index x + 4 or x
-    const f4a v0 = *reinterpret_cast<const f4a*>(&lds[0][ty + 1][x + 4]);
-    const f4a v1 = *reinterpret_cast<const f4a*>(&lds[1][ty + 1][x]);
-    const f4a v2 = *reinterpret_cast<const f4a*>(&lds[2][ty][x + 4]);
-    const f4a v3 = *reinterpret_cast<const f4a*>(&lds[3][ty + 1][x + 4]);
-    const f4a v4 = *reinterpret_cast<const f4a*>(&lds[4][ty + 2][x + 4]);
+    const f4a v0 = *reinterpret_cast<const f4a*>(&lds[0][ty][x]);
+    const f4a v1 = *reinterpret_cast<const f4a*>(&lds[1][ty][x]);
+    const f4a v2 = *reinterpret_cast<const f4a*>(&lds[2][ty][x]);
+    const f4a v3 = *reinterpret_cast<const f4a*>(&lds[3][ty][x]);
+    const f4a v4 = *reinterpret_cast<const f4a*>(&lds[4][ty][x]);
     const f4a v5 = *reinterpret_cast<const f4a*>(&lds[5][ty][x]);
-    const f4a v6 = *reinterpret_cast<const f4a*>(&lds[6][ty][x + 4]);
-    const f4a v7 = *reinterpret_cast<const f4a*>(&lds[7][ty + 2][x + 4]);
-    const f4a v8 = *reinterpret_cast<const f4a*>(&lds[8][ty + 2][x]);
+    const f4a v6 = *reinterpret_cast<const f4a*>(&lds[6][ty][x]);
+    const f4a v7 = *reinterpret_cast<const f4a*>(&lds[7][ty][x]);
+    const f4a v8 = *reinterpret_cast<const f4a*>(&lds[8][ty][x]);
 #define LBM_UNPACK(k, v) o[k][0] = v.x; o[k][1] = v.y; o[k][2] = v.z; o[k][3] = v.w;
     LBM_UNPACK(0, v0) LBM_UNPACK(1, v1) LBM_UNPACK(2, v2) LBM_UNPACK(3, v3) LBM_UNPACK(4, v4)
     LBM_UNPACK(5, v5) LBM_UNPACK(6, v6) LBM_UNPACK(7, v7) LBM_UNPACK(8, v8)
