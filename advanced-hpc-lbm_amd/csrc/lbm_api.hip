@@ -954,7 +954,7 @@ namespace {
 
 // End of a run: reduce across ranks (if there is a communicator), wait, fetch the per-step sums.
 int collect_sums(lbm_ctx* c, int nsteps, float* av_vels, std::chrono::steady_clock::time_point wall0) {
-  if (c->rank_mode && c->nranks > 1 && !c->no_comm) {
+  if (c->rank_mode && c->slabs[0].comm != nullptr) {   // (a ring of one rank has a communicator too: identity)
     Slab& s = c->slabs[0];
     NCCLC(rccl::AllReduce(s.sums, s.sums, (size_t)nsteps, rccl::kFloat64, rccl::kSum, s.comm, s.sc));
   }
@@ -1253,7 +1253,7 @@ static int derive_all(lbm_ctx* c, float* out4, double* speed_sum, double* mass) 
     hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, part, grid, res);
     hipLaunchKernelGGL(lbm::lbm_fold_double, dim3(1), dim3(lbm::kBlock), 0, s.sc, mpart, grid, res + 1);
     HIPC(hipGetLastError());
-    if (c->rank_mode && c->nranks > 1 && !c->no_comm)
+    if (c->rank_mode && s.comm != nullptr)
       NCCLC(rccl::AllReduce(res, res, 2, rccl::kFloat64, rccl::kSum, s.comm, s.sc));
     HIPC(hipStreamSynchronize(s.sc));
     double h[2];

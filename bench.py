@@ -104,7 +104,8 @@ def choose_exchange(p, ob, world, rank, local_rank):
         return L.EXCHANGE_AUTO, "none (periodic self-wrap)"
     if os.environ.get("LBM_BENCH_EXCHANGE", "") == "rccl":
         return L.EXCHANGE_RCCL, "RCCL send/recv (forced by LBM_BENCH_EXCHANGE)"
-    results, note = {}, ""
+    results, speed, note = {}, {}, ""
+    probe_steps = 400 if p.nx * p.ny <= (1 << 22) else 40
     for mode in (L.EXCHANGE_RCCL, L.EXCHANGE_P2P):
         ok, st, av = True, None, None
         try:
@@ -114,6 +115,14 @@ def choose_exchange(p, ob, world, rank, local_rank):
             if ok:
                 av = np.concatenate([lat.run(6), lat.run(3)])   # pairs, and an odd run: trailing single step
                 st = lat.read_state()
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                lat.run(probe_steps)                            # which transport is faster HERE
+                dist.barrier()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                speed[mode] = t.item()
         except L.LbmError as e:
             ok, note = False, str(e)
         ok = all_ranks_agree(ok, world)
@@ -129,6 +138,10 @@ def choose_exchange(p, ob, world, rank, local_rank):
         results[mode] = (st, av)
     same = np.array_equal(results[L.EXCHANGE_RCCL][0].view(np.uint32), results[L.EXCHANGE_P2P][0].view(np.uint32)) and \
         np.array_equal(results[L.EXCHANGE_RCCL][1].view(np.uint32), results[L.EXCHANGE_P2P][1].view(np.uint32))
+    if all_ranks_agree(same, world) and speed[L.EXCHANGE_P2P] > 1.05 * speed[L.EXCHANGE_RCCL]:
+        return L.EXCHANGE_RCCL, ("RCCL send/recv, 9*nx floats per direction per pair of steps (peer-to-peer halos passed the "
+                                 "self-check but were slower here: %.1f vs %.1f ms per %d steps)"
+                                 % (speed[L.EXCHANGE_P2P] * 1e3, speed[L.EXCHANGE_RCCL] * 1e3, probe_steps))
     if all_ranks_agree(same, world):
         return L.EXCHANGE_P2P, ("peer-to-peer: edge tiles store 9*nx floats per direction per PAIR of steps straight into the "
                                 "neighbour's halo block over xGMI, in-kernel flags (self-check at start-up: bit-identical to RCCL send/recv)")
