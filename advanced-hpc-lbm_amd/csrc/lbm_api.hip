@@ -236,10 +236,12 @@ int slab_alloc(lbm_ctx* c, Slab& s, bool exchanging) {
   HIPC(hipSetDevice(s.dev));
   const int nx = c->p.nx;
   s.pitch = (nx + 63) / 64 * 64;
-  // Plane stride: rows + 4 KiB.  A power-of-two stride (8192^2: exactly 256 MiB) puts the
-  // same cell of all nine planes on the same HBM channel; 4 KiB of padding spreads the 18
-  // concurrent streams (kbench: plain 9-plane copy 4.9 -> 5.4 TB/s, sweep 5.35 -> 5.6 TB/s).
-  s.plane = (long)s.nyl * s.pitch + 1024;
+  // Plane stride: rows + 20.25 KiB.  A power-of-two stride (8192^2: exactly 256 MiB) puts the
+  // same cell of all nine planes on the same HBM channel; a few KiB of padding spread the 18
+  // concurrent streams (kbench: plain 9-plane copy 4.9 -> 5.4 TB/s, sweep 5.35 -> 5.6 TB/s with
+  // 4 KiB; a sweep over pads on two boxes put 5 x 4 KiB + 256 B at or next to the best for the
+  // copy, the one-step and the two-step kernels, 2-8 % ahead of 4 KiB).
+  s.plane = (long)s.nyl * s.pitch + 5184;
   const size_t lat_bytes = sizeof(float) * 9 * (size_t)s.plane;
   for (int i = 0; i < 2; ++i) HIPC(hipMalloc((void**)&s.lat[i], lat_bytes));
   HIPC(hipMalloc((void**)&s.blocked, (size_t)s.plane));
