@@ -548,3 +548,73 @@ def test_peer_to_peer_halos_between_processes(gpu, tmp_path, nranks):
     st2 = np.concatenate([np.load(tmp_path / f"state_{r}.npy") for r in range(nranks)], axis=0)
     assert np.array_equal(st1.view(np.uint32), st2.view(np.uint32))
     assert np.allclose(av1, av2, rtol=2e-6, atol=0)
+
+
+def _random_lattice(L, O, nx, ny, seed, blocked=0.15):
+    rng = np.random.default_rng(seed)
+    p = L.Param(nx, ny, 9, 3, 0.1, 0.02, 1.7)
+    op = O.OrcParam(nx, ny, 9, 3, float(p.density), float(p.accel), float(p.omega))
+    ob = (rng.random((ny, nx)) < blocked).astype(np.int32)
+    w = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4)
+    c0 = (w * 0.1 * (1 + 0.2 * (rng.random((ny, nx, 9)) - 0.5))).astype(np.float32)
+    return p, op, ob, c0
+
+
+@pytest.mark.parametrize("nx,ny", [(64, 16), (64, 32), (128, 16), (192, 48)])
+def test_two_step_kernel_smallest_tilings(gpu, O, oracle, nx, ny):
+    """One tile (its ring wraps onto itself in both directions), one tile row, one tile column."""
+    L = gpu
+    p, op, ob, c0 = _random_lattice(L, O, nx, ny, nx + ny)
+    ref = c0.copy()
+    av_o = oracle.run(op, ref, ob, 11)
+    with L.Lattice(p, ob, c0) as lat:
+        assert lat.info("time_block_active") == 2
+        av = np.concatenate([lat.run(4), lat.run(7)])
+        st = lat.read_state()
+    assert np.all(np.abs(st - ref) <= 2e-5 * np.abs(ref))
+    assert np.allclose(av, av_o, rtol=2e-5, atol=0)
+
+
+@pytest.mark.parametrize("exchange", ["copy", "p2p"])
+@pytest.mark.parametrize("nx,ny,nslabs", [(64, 32, 2), (128, 48, 3), (64, 64, 2)])
+def test_two_step_slabs_of_one_and_two_tile_rows(gpu, O, oracle, exchange, nx, ny, nslabs):
+    """Slabs of a single tile row (both of its edges face a neighbour: it waits for, and feeds, both
+    sides) and of two tile rows (no interior launch), against the float oracle and the undivided run."""
+    L = gpu
+    p, op, ob, c0 = _random_lattice(L, O, nx, ny, 7 * nx + ny + nslabs)
+    ref = c0.copy()
+    av_o = oracle.run(op, ref, ob, 13)
+    mode = L.EXCHANGE_COPY if exchange == "copy" else L.EXCHANGE_P2P
+    with L.Lattice(p, ob, c0) as lat:
+        st1 = (lat.run(13), lat.read_state())[1]
+    with L.Lattice(p, ob, c0, nslabs=nslabs, devices=[0] * nslabs, exchange=mode) as lat:
+        assert lat.info("time_block_active") == 2
+        av = np.concatenate([lat.run(6), lat.run(7)])
+        st = lat.read_state()
+    assert np.array_equal(st.view(np.uint32), st1.view(np.uint32))
+    assert np.all(np.abs(st - ref) <= 2e-5 * np.abs(ref))
+    assert np.allclose(av, av_o, rtol=2e-5, atol=0)
+
+
+def test_option_and_argument_errors(gpu):
+    L = gpu
+    pf, of = deck_paths("128x128")
+    p = L.read_params(pf)
+    ob = L.read_obstacles(of, p)
+    with L.Lattice(p, ob) as lat:
+        for key, val in (("vector_width", 3), ("kernel_variant", 8), ("time_block", 3), ("no_such_option", 1)):
+            with pytest.raises(L.LbmError):
+                lat.set_option(key, val)
+        with pytest.raises(L.LbmError):
+            lat.info("no_such_key")
+        with pytest.raises(L.LbmError):
+            lat.run(-1)
+        assert lat.run(0).size == 0
+        with pytest.raises(L.LbmError, match="not a peer-to-peer rank context"):
+            lat.p2p_handle()
+    with pytest.raises(L.LbmError, match="at least 2 rows per slab"):
+        L.Lattice(p, ob, nslabs=128, devices=[0] * 128, exchange=L.EXCHANGE_P2P)
+    with pytest.raises(L.LbmError, match="only 1 visible|not visible|wants HIP device"):
+        L.Lattice(p, ob, nslabs=2, devices=[0, 63])
+    with pytest.raises(L.LbmError, match="nslabs must be"):
+        L.Lattice(p, ob, nslabs=129, devices=[0] * 129)
