@@ -113,10 +113,12 @@ struct Slab {
   uint8_t* blocked = nullptr;
   uint8_t* blocked_gs = nullptr;   // blocked map of the row below the slab (global row0-1) ...
   uint8_t* blocked_gn = nullptr;   // ... and of the row above it (two-step kernel ring rows)
-  float* ghost_s[2] = {nullptr, nullptr};  // halo received from the south neighbour: planes 2,5,6
-  float* ghost_n[2] = {nullptr, nullptr};  // halo received from the north neighbour: planes 4,7,8
-  float* send_s[2] = {nullptr, nullptr};   // own row 0, planes 4,7,8 (goes south)
-  float* send_n[2] = {nullptr, nullptr};   // own row nyl-1, planes 2,5,6 (goes north)
+  // Halo buffers, nine slots of nx floats each (layout: lbm_kernels.hip.h, kHaloSlots), one pair
+  // per launch parity.  One-step launches move slots 3..5 only.
+  float* ghost_s[2] = {nullptr, nullptr};  // received from the south neighbour (its top rows)
+  float* ghost_n[2] = {nullptr, nullptr};  // received from the north neighbour (its bottom rows)
+  float* send_s[2] = {nullptr, nullptr};   // own rows 0, 1 packed for the south neighbour (RCCL / copy transports)
+  float* send_n[2] = {nullptr, nullptr};   // own rows nyl-1, nyl-2 packed for the north neighbour
   float* partials[2] = {nullptr, nullptr};
   int partial_cap = 0;
   double* sums = nullptr;      // one double per step of the current run
@@ -200,8 +202,7 @@ void slab_free_halos(Slab& s) {
 int slab_alloc_halos(lbm_ctx* c, Slab& s) {
   HIPC(hipSetDevice(s.dev));
   const int nx = c->p.nx;
-  const bool exchanging = true;
-  if (exchanging && c->exchange == LBM_EXCHANGE_P2P) {
+  if (c->exchange == LBM_EXCHANGE_P2P) {
     HIPC(hipMalloc((void**)&s.blocked_gs, (size_t)nx));
     HIPC(hipMalloc((void**)&s.blocked_gn, (size_t)nx));
     s.halo_bytes = (sizeof(float) * lbm::kHaloSlots * (size_t)nx + 255) / 256 * 256;
@@ -218,7 +219,7 @@ int slab_alloc_halos(lbm_ctx* c, Slab& s) {
       s.ghost_s[i] = (float*)(s.comm_block + (size_t)i * s.halo_bytes);
       s.ghost_n[i] = (float*)(s.comm_block + (size_t)(2 + i) * s.halo_bytes);
     }
-  } else if (exchanging) {
+  } else {
     const size_t hb = sizeof(float) * lbm::kHaloSlots * (size_t)nx;
     HIPC(hipMalloc((void**)&s.blocked_gs, (size_t)nx));
     HIPC(hipMalloc((void**)&s.blocked_gn, (size_t)nx));
