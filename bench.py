@@ -107,7 +107,7 @@ def choose_exchange(p, ob, world, rank, local_rank):
     results, speed, note = {}, {}, ""
     probe_steps = 400 if p.nx * p.ny <= (1 << 22) else 40
     for mode in (L.EXCHANGE_RCCL, L.EXCHANGE_P2P):
-        ok, st, av = True, None, None
+        ok, st, av, lat = True, None, None, None
         try:
             lat = make_lattice(p, ob, world, rank, local_rank, mode)
             if mode == L.EXCHANGE_P2P and int(lat.info("exchange")) != L.EXCHANGE_P2P:
@@ -123,14 +123,15 @@ def choose_exchange(p, ob, world, rank, local_rank):
                 t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 speed[mode] = t.item()
-        except L.LbmError as e:
-            ok, note = False, str(e)
+        except Exception as e:   # anything at all in the peer-to-peer probe means: use RCCL
+            ok, note = False, f"{type(e).__name__}: {e}"
         ok = all_ranks_agree(ok, world)
         dist.barrier()
         try:
             lat.close()
         except Exception:
             pass
+        lat = None
         if not ok:
             if mode == L.EXCHANGE_RCCL:
                 raise SystemExit(f"RCCL halo exchange failed: {note}")
