@@ -107,35 +107,47 @@ def choose_exchange(p, ob, world, rank, local_rank):
     results, speed, note = {}, {}, ""
     probe_steps = 400 if p.nx * p.ny <= (1 << 22) else 40
     for mode in (L.EXCHANGE_RCCL, L.EXCHANGE_P2P):
+        # every rank walks through the same collectives whatever happens to it: library calls sit in
+        # try blocks, the agreement all-reduces between them
         ok, st, av, lat = True, None, None, None
         try:
             lat = make_lattice(p, ob, world, rank, local_rank, mode)
             if mode == L.EXCHANGE_P2P and int(lat.info("exchange")) != L.EXCHANGE_P2P:
-                ok = False          # the library itself fell back (no peer mapping on some rank)
-            if ok:
-                av = np.concatenate([lat.run(6), lat.run(3)])   # pairs, and an odd run: trailing single step
-                st = lat.read_state()
-                dist.barrier()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                lat.run(probe_steps)                            # which transport is faster HERE
-                dist.barrier()
-                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                speed[mode] = t.item()
-        except Exception as e:   # anything at all in the peer-to-peer probe means: use RCCL
+                ok, note = False, "no peer mapping on some rank (library fell back)"
+        except Exception as e:
             ok, note = False, f"{type(e).__name__}: {e}"
         ok = all_ranks_agree(ok, world)
+        if ok:
+            try:
+                av = np.concatenate([lat.run(6), lat.run(3)])   # pairs, and an odd run: trailing single step
+                st = lat.read_state()
+            except Exception as e:
+                ok, note = False, f"{type(e).__name__}: {e}"
+            ok = all_ranks_agree(ok, world)
+        if ok:
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            try:
+                lat.run(probe_steps)                            # which transport is faster HERE
+            except Exception as e:
+                ok, note = False, f"{type(e).__name__}: {e}"
+            dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            speed[mode] = t.item()
+            ok = all_ranks_agree(ok, world)
         dist.barrier()
         try:
-            lat.close()
+            if lat is not None:
+                lat.close()
         except Exception:
             pass
         lat = None
         if not ok:
             if mode == L.EXCHANGE_RCCL:
                 raise SystemExit(f"RCCL halo exchange failed: {note}")
-            return L.EXCHANGE_RCCL, "RCCL send/recv (peer-to-peer self-check could not run: %s)" % (note or "no peer mapping")
+            return L.EXCHANGE_RCCL, "RCCL send/recv (peer-to-peer self-check could not run: %s)" % (note or "failure on another rank")
         results[mode] = (st, av)
     same = np.array_equal(results[L.EXCHANGE_RCCL][0].view(np.uint32), results[L.EXCHANGE_P2P][0].view(np.uint32)) and \
         np.array_equal(results[L.EXCHANGE_RCCL][1].view(np.uint32), results[L.EXCHANGE_P2P][1].view(np.uint32))
