@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -156,6 +157,7 @@ struct lbm_ctx {
   int V = 1;                   // cells per thread
   long variant = 0;
   int time_block = 1;          // 2: fuse pairs of steps through LDS (lbm_sweep2) where eligible
+  int t2_threads = 256;        // threads per tile of the two-step kernel (256 / 512 / 1024)
   uint32_t seq = 0;            // peer-to-peer: sequence number of the last launch group (same on all slabs)
   bool p2p_connected = false;
   bool no_comm = false;        // rank mode without RCCL: results are this rank's contribution
@@ -344,10 +346,22 @@ void pick_defaults(lbm_ctx* c) {
   // Two steps per pass through LDS: 1.4x (1024^2) to 1.65x (8192^2) over the single-step
   // sweep (kbench); nontemporal stores only pay off when the lattice streams from HBM.
   c->time_block = 2;
+  // Threads per 64 x 16 tile of the two-step kernel (tools/t2_threads_check.py,
+  // tools/strong_scaling_proxy.py): 512 (2 cells per thread and phase, 62 VGPRs, 32 waves per CU)
+  // beats 256 on every lattice alone on a GPU -- 1024^2 8.7 -> 7.6 us/step, 128^2/256^2 4.1 -> 3.3,
+  // 8192^2 equal -- and on slabs; a slab with at most one tile per CU (1024 x 128 on one of 8
+  // GPUs) is bound by a single block's serial chain and does best with 1024 (4.6 -> 4.3 us/step).
+  c->t2_threads = 512;
+  if (c->exchange != 0) {
+    long tiles = 0;
+    for (auto& s : c->slabs) tiles = std::max(tiles, (long)(nx / kT2X) * (s.nyl / kT2Y));
+    if (tiles <= 256) c->t2_threads = 1024;
+  }
   const char* e;
   if ((e = getenv("LBM_VECTOR_WIDTH"))) c->V = pick_vector_width(nx);
   if ((e = getenv("LBM_KERNEL_VARIANT"))) c->variant = atol(e) & 7;
   if ((e = getenv("LBM_TIME_BLOCK"))) c->time_block = atoi(e) == 2 ? 2 : 1;
+  if ((e = getenv("LBM_T2_THREADS"))) { const int t = atoi(e); if (t == 256 || t == 512 || t == 1024) c->t2_threads = t; }
 }
 
 // The two-step kernel covers whole 64 x 16 tiles.  With neighbours every slab must tile too,
@@ -358,19 +372,28 @@ bool t2_eligible(const lbm_ctx* c) {
   return c->p.ny % (c->nranks * kT2Y) == 0;
 }
 
+template <int MODE, int KIND, int NT>
+void launch_sweep2_mkn(const lbm::Sweep2Args& a, int grid, hipStream_t st) {
+  hipLaunchKernelGGL((lbm::lbm_sweep2<kT2X, kT2Y, MODE, KIND, NT>), dim3(grid), dim3(NT), 0, st, a);
+}
+
 template <int MODE, int KIND>
-void launch_sweep2_mk(const lbm::Sweep2Args& a, int grid, hipStream_t st) {
-  hipLaunchKernelGGL((lbm::lbm_sweep2<kT2X, kT2Y, MODE, KIND>), dim3(grid), dim3(lbm::kBlock), 0, st, a);
+void launch_sweep2_mk(const lbm_ctx* c, const lbm::Sweep2Args& a, int grid, hipStream_t st) {
+  switch (c->t2_threads) {   // threads per tile: see lbm_sweep2
+    case 1024: launch_sweep2_mkn<MODE, KIND, 1024>(a, grid, st); break;
+    case 512: launch_sweep2_mkn<MODE, KIND, 512>(a, grid, st); break;
+    default: launch_sweep2_mkn<MODE, KIND, 256>(a, grid, st); break;
+  }
 }
 
 template <int KIND>
 void launch_sweep2_k(const lbm_ctx* c, const lbm::Sweep2Args& a, int grid, hipStream_t st) {
   // cache-resident lattices: default policy; streamed lattices: nontemporal stores (kbench)
   switch ((int)(c->variant & (lbm::kFastMath | lbm::kNtStore))) {
-    case 0: launch_sweep2_mk<0, KIND>(a, grid, st); break;
-    case 1: launch_sweep2_mk<1, KIND>(a, grid, st); break;
-    case 2: launch_sweep2_mk<2, KIND>(a, grid, st); break;
-    default: launch_sweep2_mk<3, KIND>(a, grid, st); break;
+    case 0: launch_sweep2_mk<0, KIND>(c, a, grid, st); break;
+    case 1: launch_sweep2_mk<1, KIND>(c, a, grid, st); break;
+    case 2: launch_sweep2_mk<2, KIND>(c, a, grid, st); break;
+    default: launch_sweep2_mk<3, KIND>(c, a, grid, st); break;
   }
 }
 
@@ -1343,6 +1366,11 @@ extern "C" int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     c->V = (int)value;
     return LBM_OK;
   }
+  if (!strcmp(key, "t2_threads")) {
+    if (value != 256 && value != 512 && value != 1024) return fail(LBM_EINVAL, "t2_threads must be 256, 512 or 1024");
+    c->t2_threads = (int)value;
+    return LBM_OK;
+  }
   if (!strcmp(key, "time_block")) {
     if (value != 1 && value != 2) return fail(LBM_EINVAL, "time_block must be 1 or 2");
     c->time_block = (int)value;
@@ -1361,6 +1389,7 @@ extern "C" int lbm_get_info(const lbm_ctx* c, const char* key, double* value) {
   if (!strcmp(key, "vector_width")) { *value = c->V; return LBM_OK; }
   if (!strcmp(key, "kernel_variant")) { *value = (double)c->variant; return LBM_OK; }
   if (!strcmp(key, "time_block")) { *value = c->time_block; return LBM_OK; }
+  if (!strcmp(key, "t2_threads")) { *value = c->t2_threads; return LBM_OK; }
   if (!strcmp(key, "time_block_active")) { *value = t2_eligible(c) ? 2 : 1; return LBM_OK; }
   if (!strcmp(key, "fluid_cells")) { *value = (double)c->tot_fluid; return LBM_OK; }
   if (!strcmp(key, "exchange")) { *value = c->exchange; return LBM_OK; }

@@ -63,8 +63,8 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// Block-wide sum; result valid in thread 0.  `red` holds one slot per wave.
-template <typename T>
+// Block-wide sum; result valid in thread 0.  `red` holds one slot per wave (NW waves per block).
+template <typename T, int NW = kBlock / 64>
 __device__ __forceinline__ T block_sum(T v, T* red) {
   v = wave_sum(v);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -73,7 +73,7 @@ __device__ __forceinline__ T block_sum(T v, T* red) {
   T r = T(0);
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) r += red[w];
+    for (int w = 0; w < NW; ++w) r += red[w];
   }
   return r;
 }
@@ -498,7 +498,7 @@ __device__ __forceinline__ void tile_order(int idx, int ntx, int nrows, int& row
 
 // Phase A gather of lbm_sweep2: the nine pulled values, blocked flag and region coordinates of the
 // cells this thread computes for step t+1.  E = the tile row borders a neighbouring slab.
-template <int TX, int TY, bool NTL, bool E, int NA>
+template <int TX, int TY, bool NTL, bool E, int NA, int NT>
 __device__ __forceinline__ void sweep2_gather(const Sweep2Args& a, int X0, int Y0, float (&q)[NA][9], bool (&blk)[NA],
                                               int (&cxs)[NA], int (&cys)[NA]) {
   constexpr int IW = TX + 2, IH = TY + 2;
@@ -506,7 +506,7 @@ __device__ __forceinline__ void sweep2_gather(const Sweep2Args& a, int X0, int Y
   const float* s = a.src;
 #pragma unroll
   for (int m = 0; m < NA; ++m) {
-    const int idx = threadIdx.x + m * kBlock;
+    const int idx = threadIdx.x + m * NT;
     const int cy = idx / IW, cx = idx - cy * IW;
     cxs[m] = cx; cys[m] = cy;
     if (idx < IW * IH) {
@@ -569,31 +569,40 @@ __device__ __forceinline__ void sweep2_gather(const Sweep2Args& a, int X0, int Y
 // is alone and wraps periodically in y.  EDGE = true: first / last tile row of a slab with
 // neighbours; rows -2, -1, ny, ny+1 come from the halo buffers and the new edge rows are also
 // packed for the neighbours.
-template <int TX, int TY, int MODE, int KIND = kSweep2Plain>
-__global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
+//
+// NT = threads per block.  256 (4 cells per thread in phase B, ~5 in phase A) keeps four blocks on a
+// CU and is what a lattice that fills the chip wants.  A slab so small that each CU holds one block
+// (1024 x 128 on one of 8 GPUs: 128 tiles for 256 CUs) is bound by that single block's load ->
+// collide -> LDS -> collide -> store chain; 512 or 1024 threads per tile cut the serial work per
+// thread to 2 or 1 cells per phase and give the CU's SIMDs 2 or 4 waves each to interleave.
+template <int TX, int TY, int MODE, int KIND = kSweep2Plain, int NT = kBlock>
+__global__ __launch_bounds__(NT) void lbm_sweep2(const Sweep2Args a) {
   constexpr bool EDGE = (KIND == kSweep2Edge);
-  static_assert((TX / 4) * TY == kBlock, "phase B: one thread per 4 cells of the tile");
+  constexpr int V = TX * TY / NT;                  // cells per thread in phase B
+  static_assert(V * NT == TX * TY && (V == 4 || V == 2 || V == 1), "phase B: V = 4, 2 or 1 cells per thread");
+  static_assert(TX % V == 0 && NT % 64 == 0, "whole waves, whole vectors per row");
   static_assert(TY >= 2, "rows 0,1 (and ny-2, ny-1) must sit in one tile row");
   constexpr bool FAST = (MODE & kFastMath) != 0;
   constexpr bool NTL = (MODE & kNtLoad) != 0, NTS = (MODE & kNtStore) != 0;
+  constexpr int NW = NT / 64;
   constexpr int IW = TX + 2, IH = TY + 2;          // step-t+1 region: tile + ring
-  constexpr int NA = (IW * IH + kBlock - 1) / kBlock;
+  constexpr int NA = (IW * IH + NT - 1) / NT;
   // LDS holds, per plane k, exactly the TX x TY values phase B will pull: the value f_k of region
   // cell P is wanted by the tile cell P + c_k only, so it is stored at THAT cell's coordinates (and
   // dropped if P + c_k falls outside the tile -- most components of the ring cells).  36 KB for a
   // 64 x 16 tile -> 4 blocks per CU, and every phase-B pull is an aligned ds_read_b128 at the
   // thread's own coordinates.
   __shared__ __attribute__((aligned(16))) float lds[9][TY][TX];
-  __shared__ float red_f[kBlock / 64];
-  __shared__ float red_g[kBlock / 64];
-  __shared__ double red_d[kBlock / 64];
+  __shared__ float red_f[NW];
+  __shared__ float red_g[NW];
+  __shared__ double red_d[NW];
 
   if (blockIdx.x == 0 && a.prev1 != nullptr) {
     double s1 = 0.0, s2 = 0.0;
-    for (int i = threadIdx.x; i < a.prev_count; i += kBlock) { s1 += (double)a.prev1[i]; s2 += (double)a.prev2[i]; }
-    s1 = block_sum<double>(s1, red_d);
+    for (int i = threadIdx.x; i < a.prev_count; i += NT) { s1 += (double)a.prev1[i]; s2 += (double)a.prev2[i]; }
+    s1 = block_sum<double, NW>(s1, red_d);
     __syncthreads();
-    s2 = block_sum<double>(s2, red_d);
+    s2 = block_sum<double, NW>(s2, red_d);
     if (threadIdx.x == 0) { a.prev_sum[0] = s1; a.prev_sum[1] = s2; }
     __syncthreads();
   }
@@ -648,12 +657,12 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
   // The gather is instantiated twice with the edge decision as a compile-time constant, chosen
   // once per block: with a run-time test inside the cell loop the loads of different cells are
   // separated by branches and no longer issue back to back (8192^2: 502 -> 592 us per step).
-  if (edge) sweep2_gather<TX, TY, NTL, true, NA>(a, X0, Y0, q, blk, cxs, cys);
-  else sweep2_gather<TX, TY, NTL, false, NA>(a, X0, Y0, q, blk, cxs, cys);
+  if (edge) sweep2_gather<TX, TY, NTL, true, NA, NT>(a, X0, Y0, q, blk, cxs, cys);
+  else sweep2_gather<TX, TY, NTL, false, NA, NT>(a, X0, Y0, q, blk, cxs, cys);
   float sum1 = 0.f;
 #pragma unroll
   for (int m = 0; m < NA; ++m) {
-    const int idx = threadIdx.x + m * kBlock;
+    const int idx = threadIdx.x + m * NT;
     if (idx < IW * IH) {
       const int cx = cxs[m], cy = cys[m] & 0xffff;
       float sp = collide_cell<FAST>(q[m], blk[m], a.omega);
@@ -677,33 +686,30 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
   }
   __syncthreads();
 
-  // ---- phase B: step t+2 on the tile, pulled from LDS
-  const int tx = threadIdx.x % (TX / 4), ty = threadIdx.x / (TX / 4);
-  const int x = 4 * tx;
+  // ---- phase B: step t+2 on the tile, pulled from LDS; V consecutive cells per thread
+  using RB = Row<V, false, NTS>;
+  using RH = Row<V, false, false>;
+  const int tx = threadIdx.x % (TX / V), ty = threadIdx.x / (TX / V);
+  const int x = V * tx;
   const int gy = Y0 + ty;
-  const long rc = (long)gy * a.pitch + X0 + x;
-  float o[9][4];
-  {
-    const f4a v0 = *reinterpret_cast<const f4a*>(&lds[0][ty][x]);
-    const f4a v1 = *reinterpret_cast<const f4a*>(&lds[1][ty][x]);
-    const f4a v2 = *reinterpret_cast<const f4a*>(&lds[2][ty][x]);
-    const f4a v3 = *reinterpret_cast<const f4a*>(&lds[3][ty][x]);
-    const f4a v4 = *reinterpret_cast<const f4a*>(&lds[4][ty][x]);
-    const f4a v5 = *reinterpret_cast<const f4a*>(&lds[5][ty][x]);
-    const f4a v6 = *reinterpret_cast<const f4a*>(&lds[6][ty][x]);
-    const f4a v7 = *reinterpret_cast<const f4a*>(&lds[7][ty][x]);
-    const f4a v8 = *reinterpret_cast<const f4a*>(&lds[8][ty][x]);
-#define LBM_UNPACK(k, v) o[k][0] = v.x; o[k][1] = v.y; o[k][2] = v.z; o[k][3] = v.w;
-    LBM_UNPACK(0, v0) LBM_UNPACK(1, v1) LBM_UNPACK(2, v2) LBM_UNPACK(3, v3) LBM_UNPACK(4, v4)
-    LBM_UNPACK(5, v5) LBM_UNPACK(6, v6) LBM_UNPACK(7, v7) LBM_UNPACK(8, v8)
-#undef LBM_UNPACK
+  const long rrow = (long)gy * a.pitch;
+  float o[9][V];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) RH::ld(&lds[k][ty][0], x, o[k]);   // aligned ds_read_b128 / b64 / b32
+  bool ob[V];
+  if constexpr (V == 4) {
+    const uint32_t mb = *reinterpret_cast<const uint32_t*>(a.blocked + rrow + X0 + x);
+    ob[0] = (mb & 0xffu) != 0; ob[1] = (mb & 0xff00u) != 0; ob[2] = (mb & 0xff0000u) != 0; ob[3] = (mb & 0xff000000u) != 0;
+  } else if constexpr (V == 2) {
+    const uint16_t mb = *reinterpret_cast<const uint16_t*>(a.blocked + rrow + X0 + x);
+    ob[0] = (mb & 0xffu) != 0; ob[1] = (mb & 0xff00u) != 0;
+  } else {
+    ob[0] = a.blocked[rrow + X0 + x] != 0;
   }
-  const uint32_t mb = *reinterpret_cast<const uint32_t*>(a.blocked + rc);
-  const bool ob[4] = {(mb & 0xffu) != 0, (mb & 0xff00u) != 0, (mb & 0xff0000u) != 0, (mb & 0xff000000u) != 0};
   const bool do_accel = a.accel_out && (gy == a.accel_row);
   float sum2 = 0.f;
 #pragma unroll
-  for (int v = 0; v < 4; ++v) {
+  for (int v = 0; v < V; ++v) {
     float p[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) p[k] = o[k][v];
@@ -712,21 +718,17 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) o[k][v] = p[k];
   }
-  float* d = a.dst + rc;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    f4a w; w.x = o[k][0]; w.y = o[k][1]; w.z = o[k][2]; w.w = o[k][3];
-    stg<NTS>(reinterpret_cast<f4a*>(d + k * P), w);
-  }
+  for (int k = 0; k < 9; ++k) RB::st(a.dst + k * P + rrow, X0 + x, o[k]);
   if (edge) {
     // pack the new edge rows for the neighbours (layout: kHaloSlots comment above)
     auto put = [&](float* buf, int slot, int k) {
-      float* dstp = buf + (long)slot * a.nx + X0 + x;
+      float* row = buf + (long)slot * a.nx;
       if constexpr (KIND == kSweep2P2P) {
-        p2p_store(dstp, o[k][0]); p2p_store(dstp + 1, o[k][1]); p2p_store(dstp + 2, o[k][2]); p2p_store(dstp + 3, o[k][3]);
+#pragma unroll
+        for (int v = 0; v < V; ++v) p2p_store(row + X0 + x + v, o[k][v]);
       } else {
-        f4a w; w.x = o[k][0]; w.y = o[k][1]; w.z = o[k][2]; w.w = o[k][3];
-        *reinterpret_cast<f4a*>(dstp) = w;
+        RH::st(row, X0 + x, o[k]);
       }
     };
     if (gy == 0) { put(a.send_s, 0, 0); put(a.send_s, 1, 1); put(a.send_s, 2, 3); put(a.send_s, 3, 4); put(a.send_s, 4, 7); put(a.send_s, 5, 8); }
@@ -735,8 +737,8 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep2(const Sweep2Args a) {
     if (gy == a.ny - 2) { put(a.send_n, 6, 2); put(a.send_n, 7, 5); put(a.send_n, 8, 6); }
   }
 
-  const float b1 = block_sum<float>(sum1, red_f);   // (contains a __syncthreads: all remote stores issued)
-  const float b2 = block_sum<float>(sum2, red_g);
+  const float b1 = block_sum<float, NW>(sum1, red_f);   // (contains a __syncthreads: all remote stores issued)
+  const float b2 = block_sum<float, NW>(sum2, red_g);
   if (threadIdx.x == 0) { a.partials1[blockIdx.x] = b1; a.partials2[blockIdx.x] = b2; }
   if constexpr (KIND == kSweep2P2P) {
     if (edge) {

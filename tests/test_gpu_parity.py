@@ -121,20 +121,23 @@ def test_two_step_kernel_equals_single_step_kernel(gpu, O, oracle, deck):
     cells = oracle.init_cells(op, np.float32)
     av_o = oracle.run(op, cells, ob, n)
     res = {}
-    for tb in (1, 2):
+    for tb, threads in ((1, 256), (2, 256), (2, 512), (2, 1024)):     # threads per tile of the two-step kernel
         for variant in (1, 3, 0):
             with L.Lattice(p, ob) as lat:
                 lat.set_option("time_block", tb)
+                lat.set_option("t2_threads", threads)
                 lat.set_option("kernel_variant", variant)
-                assert lat.info("time_block_active") == tb
+                assert lat.info("time_block_active") == tb and lat.info("t2_threads") == threads
                 av = np.concatenate([lat.run(n - 12), lat.run(12)])
-                res[(tb, variant)] = (av, lat.read_state())
+                res[(tb, threads, variant)] = (av, lat.read_state())
     for variant in (1, 3, 0):
-        (av1, st1), (av2, st2) = res[(1, variant)], res[(2, variant)]
-        assert np.array_equal(st1.view(np.uint32), st2.view(np.uint32)), variant
-        assert np.allclose(av1, av2, rtol=2e-6, atol=0)
-        assert np.abs(st2 - cells).max() <= 5e-5 * np.abs(cells).max()
-        assert np.allclose(av2, av_o, rtol=1e-4, atol=0)
+        av1, st1 = res[(1, 256, variant)]
+        for threads in (256, 512, 1024):
+            av2, st2 = res[(2, threads, variant)]
+            assert np.array_equal(st1.view(np.uint32), st2.view(np.uint32)), (variant, threads)
+            assert np.allclose(av1, av2, rtol=2e-6, atol=0)
+            assert np.abs(st2 - cells).max() <= 5e-5 * np.abs(cells).max()
+            assert np.allclose(av2, av_o, rtol=1e-4, atol=0)
 
 
 def test_two_step_kernel_known_answers(gpu, O):
@@ -587,13 +590,15 @@ def test_two_step_slabs_of_one_and_two_tile_rows(gpu, O, oracle, exchange, nx, n
     mode = L.EXCHANGE_COPY if exchange == "copy" else L.EXCHANGE_P2P
     with L.Lattice(p, ob, c0) as lat:
         st1 = (lat.run(13), lat.read_state())[1]
-    with L.Lattice(p, ob, c0, nslabs=nslabs, devices=[0] * nslabs, exchange=mode) as lat:
-        assert lat.info("time_block_active") == 2
-        av = np.concatenate([lat.run(6), lat.run(7)])
-        st = lat.read_state()
-    assert np.array_equal(st.view(np.uint32), st1.view(np.uint32))
-    assert np.all(np.abs(st - ref) <= 2e-5 * np.abs(ref))
-    assert np.allclose(av, av_o, rtol=2e-5, atol=0)
+    for threads in (256, 512, 1024):
+        with L.Lattice(p, ob, c0, nslabs=nslabs, devices=[0] * nslabs, exchange=mode) as lat:
+            lat.set_option("t2_threads", threads)
+            assert lat.info("time_block_active") == 2
+            av = np.concatenate([lat.run(6), lat.run(7)])
+            st = lat.read_state()
+        assert np.array_equal(st.view(np.uint32), st1.view(np.uint32)), threads
+        assert np.all(np.abs(st - ref) <= 2e-5 * np.abs(ref))
+        assert np.allclose(av, av_o, rtol=2e-5, atol=0)
 
 
 def test_option_and_argument_errors(gpu):

@@ -54,7 +54,7 @@ static void launch(const Lat& L, int cur, int q, hipStream_t st, bool accel) {
   hipLaunchKernelGGL((lbm::lbm_sweep<V, MODE>), dim3(grid), dim3(lbm::kBlock), 0, st, a);
 }
 
-template <int TX, int TY, int MODE>
+template <int TX, int TY, int MODE, int NT = 256>
 static void launch2(const Lat& L, int cur, int q, hipStream_t st, bool accel) {
   lbm::Sweep2Args a{};
   a.src = L.lat[cur]; a.dst = L.lat[cur ^ 1];
@@ -65,7 +65,7 @@ static void launch2(const Lat& L, int cur, int q, hipStream_t st, bool accel) {
   a.prev1 = a.prev2 = nullptr;
   a.by_begin = 0; a.by_count = L.ny / TY; a.by_stride = 1;
   const int grid = (L.nx / TX) * (L.ny / TY);
-  hipLaunchKernelGGL((lbm::lbm_sweep2<TX, TY, MODE>), dim3(grid), dim3(lbm::kBlock), 0, st, a);
+  hipLaunchKernelGGL((lbm::lbm_sweep2<TX, TY, MODE, lbm::kSweep2Plain, NT>), dim3(grid), dim3(NT), 0, st, a);
 }
 
 // state after `pairs` x 2 steps with the two-step kernel vs 2 x pairs single steps: must agree
@@ -141,6 +141,9 @@ int main(int argc, char** argv) {
       {"V1 fast", launch<1, kFastMath>},
       {"T2 64x16 fast", launch2<64, 16, kFastMath>, 2}, {"T2 64x16 fast nt", launch2<64, 16, kFastMath | kNtLoad | kNtStore>, 2},
       {"T2 64x16 fast nts", launch2<64, 16, kFastMath | kNtStore>, 2},
+      {"T2 64x16 fast 512t", launch2<64, 16, kFastMath, 512>, 2}, {"T2 64x16 fast 1024t", launch2<64, 16, kFastMath, 1024>, 2},
+      {"T2 64x16 nts 512t", launch2<64, 16, kFastMath | kNtStore, 512>, 2}, {"T2 64x16 nts 1024t", launch2<64, 16, kFastMath | kNtStore, 1024>, 2},
+      {"T2 128x8 fast 512t", launch2<128, 8, kFastMath, 512>, 2},
       {"T2 128x8 fast", launch2<128, 8, kFastMath>, 2}, {"T2 128x8 fast nt", launch2<128, 8, kFastMath | kNtLoad | kNtStore>, 2},
       {"T2 32x32 fast", launch2<32, 32, kFastMath>, 2}, {"T2 32x32 fast nt", launch2<32, 32, kFastMath | kNtLoad | kNtStore>, 2},
       {"T2 256x4 fast", launch2<256, 4, kFastMath>, 2},
@@ -166,7 +169,7 @@ int main(int argc, char** argv) {
     std::sort(us[v].begin(), us[v].end());
     const double med = us[v][us[v].size() / 2], mn = us[v][0];
     const double mlups = (double)n * n / med;
-    printf("%-18s median %9.2f us  min %9.2f us  %9.0f MLUPS  %7.0f GB/s  frac %.3f\n", vars[v].name, med, mn,
+    printf("%-20s median %9.2f us  min %9.2f us  %9.0f MLUPS  %7.0f GB/s  frac %.3f\n", vars[v].name, med, mn,
            mlups, mlups * 72 / 1e3, mlups * 72 / 8e6);
   }
   return 0;
