@@ -156,7 +156,10 @@ int lbm_total_density(lbm_ctx* ctx, double* out);
  * lbm_read_state in rank mode. */
 int lbm_final_state(lbm_ctx* ctx, float* out);
 
-/* Replaces: finalise(), d2q9-bgk.c:2871-2890. */
+/* Replaces: finalise(), d2q9-bgk.c:2871-2890.
+ * Rank contexts with peer-to-peer halos: the neighbours' last launches still store into this
+ * context's halo block, so destroy it only after EVERY rank's last lbm_run has returned
+ * (a barrier of the caller's choice); the RCCL and single-process forms need no such care. */
 int lbm_destroy(lbm_ctx* ctx);
 
 /*
