@@ -1,0 +1,48 @@
+"""bench.py prints exactly one JSON line with the fields the driver reads."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _run(args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_line_single_gpu(gpu):
+    d = _run(["--steps", "400", "--warmup", "20", "--also-steps", "20", "--cpu-sample-steps", "20"])
+    assert REQUIRED <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 400 and d["warmup"] == 20 and d["higher_is_better"] is True
+    assert d["unit"] == "MLUPS" and d["dtype"] == "f32" and d["vs_baseline"] is None and d["scaling"] == "strong"
+    assert "workload" in d["config"] and "1024x1024" in d["config"]["workload"] and "model" not in d["config"]
+    assert abs(d["value"] - 1024 * 1024 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
+    ro = d["roofline"]
+    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
+    assert ro["traffic"] is None or ro["traffic"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["unit"] == "MLUPS" and cb["cores"] == 1 and cb["kind"] in ("reference", "port") and cb["value"] > 1
+    assert d["results_finite"] is True
+    assert "8192x8192" in d["also"] and d["also"]["8192x8192"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_path_rehearsal(gpu):
+    """The N > 1 code path (communicator, transport self-check, peer-to-peer halos) on a ring of one rank."""
+    d = _run(["--rehearse-multi", "--steps", "400", "--warmup", "20", "--also", "", "--cpu-sample-steps", "0"])
+    assert REQUIRED <= set(d)
+    assert d["cpu_baseline"] is None
+    assert "peer-to-peer" in d["config"]["halo"] or "RCCL" in d["config"]["halo"]
+    assert "REHEARSAL" in d["config"]["decomposition"]
