@@ -195,15 +195,21 @@ def measure(name, world, rank, local_rank, steps, warmup):
     launch_s = gpu_ms * 1e-3 / launches                  # mean duration of one launch on this GPU
     bytes_per_launch = BYTES_PER_LUP * local_cells * steps / launches   # algorithmic bytes one launch covers
     achieved = bytes_per_launch / launch_s / 1e9
+    traffic = lookup_traffic(name, world, kernel)
     return {
         "mlups": cells * steps / dt / 1e6,
         "ms_per_step": dt * 1e3 / steps,
         "gpu_ms_per_step": gpu_ms / steps,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": lookup_traffic(name, world, kernel),
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "kernel": kernel, "lattice_updates_per_launch": local_cells * steps / launches,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "launch_us": round(launch_s * 1e6, 3)},
+                     "launch_us": round(launch_s * 1e6, 3),
+                     # what actually crossed the HBM interface (PMC bytes / measured launch time): the
+                     # two-step kernel moves ~38 B per update instead of the 72 B `achieved` prices, so
+                     # frac > 1 means temporal blocking, not more than the pins can carry
+                     "traffic_gbs": None if traffic is None else round(traffic / launch_s / 1e9, 1),
+                     "traffic_frac_of_peak": None if traffic is None else round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4)},
         "data": data, "params": p, "blocked": int(ob.sum()), "av_last": float(av[-1]), "finite": bool(np.isfinite(av).all()),
         "halo": halo_note,
     }
