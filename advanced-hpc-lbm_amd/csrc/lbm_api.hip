@@ -249,7 +249,7 @@ int slab_alloc(lbm_ctx* c, Slab& s, bool exchanging) {
   for (int i = 0; i < 2; ++i) HIPC(hipMalloc((void**)&s.lat[i], lat_bytes));
   HIPC(hipMalloc((void**)&s.blocked, (size_t)s.plane));
   // one partial per block; worst case V = 1, one launch covering all rows (+2 for split launches)
-  s.partial_cap = cdiv((long)s.nyl * nx, lbm::kBlock) + 4;
+  s.partial_cap = std::max(cdiv((long)s.nyl * nx, lbm::kBlock), 2 * cdiv(nx, kT2X) * cdiv(s.nyl, kT2Y)) + 8;
   for (int i = 0; i < 2; ++i) HIPC(hipMalloc((void**)&s.partials[i], sizeof(float) * s.partial_cap));
   s.scratch_cap = s.partial_cap;
   HIPC(hipMalloc((void**)&s.scratch_d, sizeof(double) * (s.scratch_cap + 8)));
@@ -367,10 +367,14 @@ void pick_defaults(lbm_ctx* c) {
 // The two-step kernel covers whole 64 x 16 tiles.  With neighbours every slab must tile too,
 // and every rank must come to the same answer (the halo message size depends on it).
 bool t2_eligible(const lbm_ctx* c) {
-  if (c->time_block != 2 || c->p.nx % kT2X != 0) return false;
-  if (c->exchange == 0) return c->slabs.size() == 1 && c->p.ny % kT2Y == 0;
-  return c->p.ny % (c->nranks * kT2Y) == 0;
+  if (c->time_block != 2) return false;
+  // a slab alone: any lattice of at least one tile (partial tiles at the east / north end)
+  if (c->exchange == 0) return c->slabs.size() == 1 && c->p.nx >= kT2X && c->p.ny >= kT2Y;
+  return c->p.nx % kT2X == 0 && c->p.ny % (c->nranks * kT2Y) == 0;
 }
+
+// Tiles of a lone slab (partial ones included).
+inline int t2_tiles(const lbm_ctx* c, int nyl) { return cdiv(c->p.nx, kT2X) * cdiv(nyl, kT2Y); }
 
 template <int MODE, int KIND, int NT>
 void launch_sweep2_mkn(const lbm::Sweep2Args& a, int grid, hipStream_t st) {
@@ -379,7 +383,9 @@ void launch_sweep2_mkn(const lbm::Sweep2Args& a, int grid, hipStream_t st) {
 
 template <int MODE, int KIND>
 void launch_sweep2_mk(const lbm_ctx* c, const lbm::Sweep2Args& a, int grid, hipStream_t st) {
-  switch (c->t2_threads) {   // threads per tile: see lbm_sweep2
+  int nt = c->t2_threads;                      // threads per tile: see lbm_sweep2
+  if (a.nx % (1024 / nt) != 0) nt = 1024;      // phase B moves 1024/nt cells per thread as one vector
+  switch (nt) {
     case 1024: launch_sweep2_mkn<MODE, KIND, 1024>(a, grid, st); break;
     case 512: launch_sweep2_mkn<MODE, KIND, 512>(a, grid, st); break;
     default: launch_sweep2_mkn<MODE, KIND, 256>(a, grid, st); break;
@@ -914,10 +920,10 @@ int launch_pair(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev, floa
   const int nx = c->p.nx;
   const int q = li & 1, qp = q ^ 1;
   const bool ex = c->exchange != 0;
-  const int ntx = nx / kT2X;
+  const int ntx = cdiv(nx, kT2X);   // (partial tiles only when the slab is alone)
   int rc;
   auto fill = [&](Slab& s, lbm::Sweep2Args& a) {
-    const int nbtot = ntx * (s.nyl / kT2Y);
+    const int nbtot = ntx * cdiv(s.nyl, kT2Y);
     a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
     a.plane = s.plane; a.pitch = s.pitch; a.nx = nx; a.ny = s.nyl;
     a.blocked = s.blocked; a.omega = c->p.omega;
@@ -933,7 +939,7 @@ int launch_pair(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev, floa
     HIPC(hipSetDevice(s.dev));
     lbm::Sweep2Args a;
     const int nbtot = fill(s, a);
-    const int nty = s.nyl / kT2Y;
+    const int nty = cdiv(s.nyl, kT2Y);
     if (fold_prev) { a.prev1 = s.partials[qp]; a.prev2 = s.partials[qp] + nbtot; a.prev_count = nbtot; a.prev_sum = s.sums + (tt - 2); }
     if (!ex) {
       a.by_begin = 0; a.by_count = nty; a.by_stride = 1;
@@ -956,7 +962,7 @@ int launch_pair(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev, floa
   if (ex) {
     if ((rc = exchange_halos(c, q, 0, lbm::kHaloSlots))) return rc;
     for (auto& s : c->slabs) {
-      const int nty = s.nyl / kT2Y;
+      const int nty = cdiv(s.nyl, kT2Y);
       HIPC(hipSetDevice(s.dev));
       const bool split = split_edge_stream(c, s);
       if (split) HIPC(hipStreamWaitEvent(s.sc, s.ev_bnd[qp], 0));
@@ -1208,7 +1214,7 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
     for (auto& s : c->slabs) {  // fold the last pair's partials
       HIPC(hipSetDevice(s.dev));
       if (ex && split_edge_stream(c, s)) HIPC(hipStreamWaitEvent(s.sc, s.ev_bnd[ql], 0));   // join the edge stream
-      const int nbtot = (nx / kT2X) * (s.nyl / kT2Y);
+      const int nbtot = cdiv(nx, kT2X) * cdiv(s.nyl, kT2Y);
       hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql], nbtot, s.sums + (tt - 2));
       hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql] + nbtot, nbtot, s.sums + (tt - 1));
       HIPC(hipGetLastError());

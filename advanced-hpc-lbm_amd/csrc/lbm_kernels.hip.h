@@ -609,7 +609,7 @@ __global__ __launch_bounds__(NT) void lbm_sweep2(const Sweep2Args a) {
 
   // XCD-aware tile order: block ids are dealt round-robin over the 8 XCDs, so give each XCD a
   // contiguous run of tiles -- x-neighbours, which share ring columns, then share an L2.
-  const int ntx = a.nx / TX;
+  const int ntx = (a.nx + TX - 1) / TX;   // a slab alone may end in partial tiles (slabs with neighbours tile exactly)
   int by, bx;
   bool edge = EDGE;            // this block's tile row borders a neighbouring slab
   if constexpr (KIND == kSweep2P2P) {
@@ -649,6 +649,11 @@ __global__ __launch_bounds__(NT) void lbm_sweep2(const Sweep2Args a) {
   }
   const int X0 = bx * TX, Y0 = by * TY;
   const long P = a.plane;
+  // Cells of this tile that exist in the lattice.  In a partial tile the region cells beyond the
+  // ring (which sits right after the last real column / row and wraps to column / row 0) are
+  // computed from wrapped, valid data and ignored.  Needs nx >= TX and ny >= TY (one wrap suffices).
+  const int wx = (a.nx - X0 < TX) ? a.nx - X0 : TX;
+  const int hy = (a.ny - Y0 < TY) ? a.ny - Y0 : TY;
 
   // ---- phase A: step t+1 on the (TX+2) x (TY+2) region -> LDS
   float q[NA][9];
@@ -667,7 +672,7 @@ __global__ __launch_bounds__(NT) void lbm_sweep2(const Sweep2Args a) {
       const int cx = cxs[m], cy = cys[m] & 0xffff;
       float sp = collide_cell<FAST>(q[m], blk[m], a.omega);
       if (cys[m] & 0x10000) accelerate_cell(q[m], blk[m], a.a1, a.a2);
-      const bool own = (cx >= 1) && (cx <= TX) && (cy >= 1) && (cy <= TY);
+      const bool own = (cx >= 1) && (cx <= wx) && (cy >= 1) && (cy <= hy);
       sum1 += own ? sp : 0.f;
       // tile coordinates of this region cell, and which neighbours exist inside the tile
       const int x0 = cx - 1, y0 = cy - 1;
@@ -692,12 +697,16 @@ __global__ __launch_bounds__(NT) void lbm_sweep2(const Sweep2Args a) {
   const int tx = threadIdx.x % (TX / V), ty = threadIdx.x / (TX / V);
   const int x = V * tx;
   const int gy = Y0 + ty;
-  const long rrow = (long)gy * a.pitch;
+  const bool live = (x < wx) && (ty < hy);        // (nx % V == 0: a vector is inside or outside as a whole)
+  const long rrow = live ? (long)gy * a.pitch : 0;
   float o[9][V];
 #pragma unroll
   for (int k = 0; k < 9; ++k) RH::ld(&lds[k][ty][0], x, o[k]);   // aligned ds_read_b128 / b64 / b32
   bool ob[V];
-  if constexpr (V == 4) {
+  if (!live) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) ob[v] = true;
+  } else if constexpr (V == 4) {
     const uint32_t mb = *reinterpret_cast<const uint32_t*>(a.blocked + rrow + X0 + x);
     ob[0] = (mb & 0xffu) != 0; ob[1] = (mb & 0xff00u) != 0; ob[2] = (mb & 0xff0000u) != 0; ob[3] = (mb & 0xff000000u) != 0;
   } else if constexpr (V == 2) {
@@ -718,8 +727,10 @@ __global__ __launch_bounds__(NT) void lbm_sweep2(const Sweep2Args a) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) o[k][v] = p[k];
   }
+  if (live) {
 #pragma unroll
-  for (int k = 0; k < 9; ++k) RB::st(a.dst + k * P + rrow, X0 + x, o[k]);
+    for (int k = 0; k < 9; ++k) RB::st(a.dst + k * P + rrow, X0 + x, o[k]);
+  }
   if (edge) {
     // pack the new edge rows for the neighbours (layout: kHaloSlots comment above)
     auto put = [&](float* buf, int slot, int k) {

@@ -141,27 +141,40 @@ def test_two_step_kernel_equals_single_step_kernel(gpu, O, oracle, deck):
 
 
 def test_two_step_kernel_known_answers(gpu, O):
-    """64x40 known answers of the reference need a lattice that tiles by 64x16: ny = 40 does
-    not, so the library must fall back to the single-step kernel there; a 64x48 random lattice
-    takes the two-step path and is checked against the float oracle."""
+    """The reference's 64x40 known answers through the two-step kernel: 40 rows are two and a half
+    tile rows, so the last tile row is partial (its ring wraps to row 0 right after row 39)."""
     L = gpu
     k, p, ob = _kat(L, O, "kat_64x40")
     with L.Lattice(p, ob, k["cells0"]) as lat:
-        assert lat.info("time_block") == 2 and lat.info("time_block_active") == 1
-    rng = np.random.default_rng(99)
-    nx, ny = 64, 48
-    p = L.Param(nx, ny, 9, 3, 0.1, 0.02, 1.7)
-    op = O.OrcParam(nx, ny, 9, 3, float(p.density), float(p.accel), float(p.omega))
-    ob = (rng.random((ny, nx)) < 0.15).astype(np.int32)
-    c0 = (np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4) * 0.1 * (1 + 0.2 * (rng.random((ny, nx, 9)) - 0.5))).astype(np.float32)
-    ref = c0.copy()
-    av_o = O.Oracle("strict").run(op, ref, ob, 9)
-    with L.Lattice(p, ob, c0) as lat:
-        assert lat.info("time_block_active") == 2
-        av = lat.run(9)
+        assert lat.info("time_block") == 2 and lat.info("time_block_active") == 2
+        av = lat.run(10)
         st = lat.read_state()
-    assert np.all(np.abs(st - ref) <= 2e-5 * np.abs(ref))
-    assert np.allclose(av, av_o, rtol=2e-5, atol=0)
+    assert np.all(np.abs(st - k["cells_after_10"]) <= 2e-5 * np.abs(k["cells_after_10"]))
+    assert np.allclose(av, k["av_vels"], rtol=2e-5, atol=0)
+    # lattices smaller than one tile take the single-step kernel
+    k, p, ob = _kat(L, O, "kat_33x20")
+    with L.Lattice(p, ob, k["cells0"]) as lat:
+        assert lat.info("time_block_active") == 1
+
+
+@pytest.mark.parametrize("nx,ny", [(65, 17), (100, 50), (130, 37), (64, 17), (200, 16), (66, 100), (1000, 600)])
+def test_two_step_kernel_partial_tiles(gpu, O, oracle, nx, ny):
+    """Lattices that do not tile by 64 x 16: partial tiles at the east / north end, odd widths (one cell
+    per thread in phase B), against the float oracle and bit for bit against the single-step kernel."""
+    L = gpu
+    p, op, ob, c0 = _random_lattice(L, O, nx, ny, 3 * nx + ny)
+    ref = c0.copy()
+    av_o = oracle.run(op, ref, ob, 9)
+    outs = {}
+    for tb in (1, 2):
+        with L.Lattice(p, ob, c0) as lat:
+            lat.set_option("time_block", tb)
+            assert lat.info("time_block_active") == tb
+            av = np.concatenate([lat.run(4), lat.run(5)])
+            outs[tb] = (av, lat.read_state())
+    assert np.array_equal(outs[1][1].view(np.uint32), outs[2][1].view(np.uint32))
+    assert np.all(np.abs(outs[2][1] - ref) <= 2e-5 * np.abs(ref))
+    assert np.allclose(outs[2][0], av_o, rtol=2e-5, atol=0)
 
 
 @pytest.mark.parametrize("nx,ny", [(30, 17), (33, 9), (2, 2), (5, 3), (64, 2), (260, 11)])
