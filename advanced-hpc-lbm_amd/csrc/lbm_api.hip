@@ -378,7 +378,13 @@ inline int t2_tiles(const lbm_ctx* c, int nyl) { return cdiv(c->p.nx, kT2X) * cd
 
 template <int MODE, int KIND, int NT>
 void launch_sweep2_mkn(const lbm::Sweep2Args& a, int grid, hipStream_t st) {
-  hipLaunchKernelGGL((lbm::lbm_sweep2<kT2X, kT2Y, MODE, KIND, NT>), dim3(grid), dim3(NT), 0, st, a);
+  if constexpr (KIND == lbm::kSweep2Plain) {
+    if (a.nx % kT2X != 0 || a.ny % kT2Y != 0) {   // lone slab that does not tile exactly
+      hipLaunchKernelGGL((lbm::lbm_sweep2<kT2X, kT2Y, MODE, KIND, NT, true>), dim3(grid), dim3(NT), 0, st, a);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((lbm::lbm_sweep2<kT2X, kT2Y, MODE, KIND, NT, false>), dim3(grid), dim3(NT), 0, st, a);
 }
 
 template <int MODE, int KIND>

@@ -575,7 +575,8 @@ __device__ __forceinline__ void sweep2_gather(const Sweep2Args& a, int X0, int Y
 // (1024 x 128 on one of 8 GPUs: 128 tiles for 256 CUs) is bound by that single block's load ->
 // collide -> LDS -> collide -> store chain; 512 or 1024 threads per tile cut the serial work per
 // thread to 2 or 1 cells per phase and give the CU's SIMDs 2 or 4 waves each to interleave.
-template <int TX, int TY, int MODE, int KIND = kSweep2Plain, int NT = kBlock>
+// PARTIAL = the lattice does not tile exactly (lone slab only): east / north tiles are cut off.
+template <int TX, int TY, int MODE, int KIND = kSweep2Plain, int NT = kBlock, bool PARTIAL = false>
 __global__ __launch_bounds__(NT) void lbm_sweep2(const Sweep2Args a) {
   constexpr bool EDGE = (KIND == kSweep2Edge);
   constexpr int V = TX * TY / NT;                  // cells per thread in phase B
@@ -652,8 +653,8 @@ __global__ __launch_bounds__(NT) void lbm_sweep2(const Sweep2Args a) {
   // Cells of this tile that exist in the lattice.  In a partial tile the region cells beyond the
   // ring (which sits right after the last real column / row and wraps to column / row 0) are
   // computed from wrapped, valid data and ignored.  Needs nx >= TX and ny >= TY (one wrap suffices).
-  const int wx = (a.nx - X0 < TX) ? a.nx - X0 : TX;
-  const int hy = (a.ny - Y0 < TY) ? a.ny - Y0 : TY;
+  const int wx = (PARTIAL && a.nx - X0 < TX) ? a.nx - X0 : TX;
+  const int hy = (PARTIAL && a.ny - Y0 < TY) ? a.ny - Y0 : TY;
 
   // ---- phase A: step t+1 on the (TX+2) x (TY+2) region -> LDS
   float q[NA][9];
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(NT) void lbm_sweep2(const Sweep2Args a) {
   const int tx = threadIdx.x % (TX / V), ty = threadIdx.x / (TX / V);
   const int x = V * tx;
   const int gy = Y0 + ty;
-  const bool live = (x < wx) && (ty < hy);        // (nx % V == 0: a vector is inside or outside as a whole)
+  const bool live = !PARTIAL || ((x < wx) && (ty < hy));   // (nx % V == 0: a vector is inside or outside as a whole)
   const long rrow = live ? (long)gy * a.pitch : 0;
   float o[9][V];
 #pragma unroll
