@@ -17,6 +17,7 @@
 ** Optional environment (the two-argument form stays unchanged):
 **   LBM_NGPUS=n        row-partition the lattice over n GPUs (default 1)
 **   LBM_EXCHANGE=rccl|p2p|copy   halo transport between slabs (default rccl)
+**   LBM_DEVICES=a,b,...      HIP device of each slab (default 0..n-1; a device may repeat)
 **   LBM_SKIP_FINAL_STATE=1   do not write final_state.dat (huge synthetic lattices)
 */
 #include <stdio.h>
@@ -160,6 +161,19 @@ int main(int argc, char* argv[])
   if ((e = getenv("LBM_EXCHANGE")) && !strcmp(e, "p2p")) exchange = LBM_EXCHANGE_P2P;
   const int skip_final = (e = getenv("LBM_SKIP_FINAL_STATE")) && atoi(e);
   if (ngpus < 1) die("LBM_NGPUS must be >= 1", __LINE__, __FILE__);
+  int* devices = NULL;
+  if ((e = getenv("LBM_DEVICES")) && *e) {
+    devices = malloc(sizeof(int) * (size_t)ngpus);
+    if (devices == NULL) die("cannot allocate memory for the device list", __LINE__, __FILE__);
+    const char* q = e;
+    for (int i = 0; i < ngpus; i++) {
+      char* end = NULL;
+      devices[i] = (int)strtol(q, &end, 10);
+      if (end == q || (i < ngpus - 1 && *end != ',') || (i == ngpus - 1 && *end != '\0'))
+        die("LBM_DEVICES must list one device per slab, comma separated", __LINE__, __FILE__);
+      q = end + 1;
+    }
+  }
 
   /* Total/init time starts here */
   tot_tic = init_tic = wtime();
@@ -169,7 +183,7 @@ int main(int argc, char* argv[])
   if (av_vels == NULL) die("cannot allocate memory for av_vels", __LINE__, __FILE__);
   lbm_ctx* ctx = NULL;
   /* NULL cells: the library starts from the rest equilibrium (d2q9-bgk.c:2802-2823) */
-  LBM_CALL(lbm_create(&params, obstacles, NULL, ngpus, NULL, exchange, &ctx));
+  LBM_CALL(lbm_create(&params, obstacles, NULL, ngpus, devices, exchange, &ctx));
 
   /* Init time stops here, compute time starts */
   init_toc = comp_tic = wtime();
@@ -209,6 +223,7 @@ int main(int argc, char* argv[])
 
   LBM_CALL(lbm_destroy(ctx));
   free(state4);
+  free(devices);
   free(av_vels);
   free(obstacles);
   return EXIT_SUCCESS;

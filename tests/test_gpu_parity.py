@@ -636,3 +636,26 @@ def test_option_and_argument_errors(gpu):
         L.Lattice(p, ob, nslabs=2, devices=[0, 63])
     with pytest.raises(L.LbmError, match="nslabs must be"):
         L.Lattice(p, ob, nslabs=129, devices=[0] * 129)
+
+
+@pytest.mark.parametrize("exchange", ["p2p", "copy"])
+def test_cli_row_partitioned(gpu, tmp_path, exchange):
+    """LBM_NGPUS / LBM_DEVICES / LBM_EXCHANGE: the CLI on two row slabs (both on this GPU) writes the
+    same final_state.dat, byte for byte, as the undivided run, and av_vels.dat within summation order."""
+    exe = os.path.join(ROOT, "d2q9-bgk")
+    pf, of = deck_paths("128x256")
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir()
+    two.mkdir()
+    r1 = subprocess.run([exe, pf, of], cwd=one, capture_output=True, text=True)
+    env = dict(os.environ, LBM_NGPUS="2", LBM_DEVICES="0,0", LBM_EXCHANGE=exchange)
+    r2 = subprocess.run([exe, pf, of], cwd=two, capture_output=True, text=True, env=env)
+    assert r1.returncode == 0 and r2.returncode == 0, r2.stderr
+    assert "GPUs:\t\t\t\t\t2" in r2.stdout
+    assert (one / "final_state.dat").read_bytes() == (two / "final_state.dat").read_bytes()
+    a1 = np.loadtxt(one / "av_vels.dat", usecols=[1])
+    a2 = np.loadtxt(two / "av_vels.dat", usecols=[1])
+    assert np.allclose(a1, a2, rtol=2e-6, atol=0)
+    bad = subprocess.run([exe, pf, of], cwd=two, capture_output=True, text=True,
+                         env=dict(os.environ, LBM_NGPUS="2", LBM_DEVICES="0"))
+    assert bad.returncode == 1 and "LBM_DEVICES must list one device per slab" in bad.stderr
