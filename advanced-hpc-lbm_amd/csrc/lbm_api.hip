@@ -20,6 +20,7 @@
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -68,7 +69,10 @@ static int (*AllGather)(const void*, void*, size_t, int, comm_t, hipStream_t);
 static const char* (*GetErrorString)(int);
 static void* handle = nullptr;
 
+static std::mutex load_mutex;
+
 static int load() {
+  std::lock_guard<std::mutex> guard(load_mutex);
   if (handle) return LBM_OK;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* n : names) {
@@ -288,6 +292,12 @@ int upload_ghost_masks(lbm_ctx* c, Slab& s, const int* obstacles) {
   return LBM_OK;
 }
 
+// A device staging buffer that is released on every path out of its scope.
+struct DeviceTemp {
+  void* p = nullptr;
+  ~DeviceTemp() { if (p) (void)hipFree(p); }
+};
+
 // Uploads the slab's rows of the global host arrays and converts to the device layout.
 int slab_upload(lbm_ctx* c, Slab& s, const int* obstacles, const float* cells) {
   HIPC(hipSetDevice(s.dev));
@@ -295,23 +305,23 @@ int slab_upload(lbm_ctx* c, Slab& s, const int* obstacles, const float* cells) {
   const long ncell = (long)s.nyl * nx;
   const int grid = cdiv(ncell, 256);
   {
-    int* d_ob = nullptr;
-    HIPC(hipMalloc((void**)&d_ob, sizeof(int) * ncell));
+    DeviceTemp t;
+    HIPC(hipMalloc(&t.p, sizeof(int) * ncell));
+    int* d_ob = (int*)t.p;
     HIPC(hipMemcpyAsync(d_ob, obstacles + (long)s.row0 * nx, sizeof(int) * ncell, hipMemcpyHostToDevice, s.sc));
     hipLaunchKernelGGL(lbm::lbm_pack_blocked, dim3(grid), dim3(256), 0, s.sc, d_ob, s.blocked, s.pitch, nx, ncell);
     HIPC(hipGetLastError());
     if (s.blocked_gs) { int rc2 = upload_ghost_masks(c, s, obstacles); if (rc2) return rc2; }
     HIPC(hipStreamSynchronize(s.sc));
-    HIPC(hipFree(d_ob));
   }
   if (cells != nullptr) {
-    float* d_aos = nullptr;
-    HIPC(hipMalloc((void**)&d_aos, sizeof(float) * 9 * ncell));
+    DeviceTemp t;
+    HIPC(hipMalloc(&t.p, sizeof(float) * 9 * ncell));
+    float* d_aos = (float*)t.p;
     HIPC(hipMemcpyAsync(d_aos, cells + 9L * s.row0 * nx, sizeof(float) * 9 * ncell, hipMemcpyHostToDevice, s.sc));
     hipLaunchKernelGGL(lbm::lbm_aos_to_soa, dim3(grid), dim3(256), 0, s.sc, d_aos, s.lat[c->cur], s.plane, s.pitch, nx, ncell);
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(s.sc));
-    HIPC(hipFree(d_aos));
   } else {
     // rest equilibrium, every cell (d2q9-bgk.c:2802-2823); padding columns get it too
     const float w0 = c->p.density * 4.f / 9.f, w1 = c->p.density / 9.f, w2 = c->p.density / 36.f;
@@ -1260,13 +1270,13 @@ extern "C" int lbm_read_state(lbm_ctx* c, float* out) {
   for (auto& s : c->slabs) {
     HIPC(hipSetDevice(s.dev));
     const long ncell = (long)s.nyl * nx;
-    float* d_aos = nullptr;
-    HIPC(hipMalloc((void**)&d_aos, sizeof(float) * 9 * ncell));
+    DeviceTemp t;
+    HIPC(hipMalloc(&t.p, sizeof(float) * 9 * ncell));
+    float* d_aos = (float*)t.p;
     hipLaunchKernelGGL(lbm::lbm_soa_to_aos, dim3(cdiv(ncell, 256)), dim3(256), 0, s.sc, s.lat[c->cur], d_aos, s.plane, s.pitch, nx, ncell);
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(s.sc));
     HIPC(hipMemcpy(out + 9L * (s.row0 - base_row) * nx, d_aos, sizeof(float) * 9 * ncell, hipMemcpyDeviceToHost));
-    HIPC(hipFree(d_aos));
   }
   return LBM_OK;
 }
@@ -1280,8 +1290,9 @@ static int derive_all(lbm_ctx* c, float* out4, double* speed_sum, double* mass) 
     HIPC(hipSetDevice(s.dev));
     const long ncell = (long)s.nyl * nx;
     const int grid = cdiv(ncell, lbm::kBlock);
-    float* d_out = nullptr;
-    if (out4) HIPC(hipMalloc((void**)&d_out, sizeof(float) * 4 * ncell));
+    DeviceTemp t;
+    if (out4) HIPC(hipMalloc(&t.p, sizeof(float) * 4 * ncell));
+    float* d_out = (float*)t.p;
     float* part = s.partials[0];  // idle between runs; capacity >= grid
     double* mpart = s.scratch_d;
     double* res = s.scratch_d + s.scratch_cap;  // 2 doubles: speed, mass
@@ -1299,7 +1310,6 @@ static int derive_all(lbm_ctx* c, float* out4, double* speed_sum, double* mass) 
     tot[0] += h[0]; tot[1] += h[1];
     if (out4) {
       HIPC(hipMemcpy(out4 + 4L * (s.row0 - base_row) * nx, d_out, sizeof(float) * 4 * ncell, hipMemcpyDeviceToHost));
-      HIPC(hipFree(d_out));
     }
   }
   if (speed_sum) *speed_sum = tot[0];
