@@ -659,3 +659,35 @@ def test_cli_row_partitioned(gpu, tmp_path, exchange):
     bad = subprocess.run([exe, pf, of], cwd=two, capture_output=True, text=True,
                          env=dict(os.environ, LBM_NGPUS="2", LBM_DEVICES="0"))
     assert bad.returncode == 1 and "LBM_DEVICES must list one device per slab" in bad.stderr
+
+
+def test_big_slabs_run_edges_on_their_own_stream(gpu):
+    """Slabs of >= 4 Mi cells launch their edge tile rows on a separate high-priority stream,
+    concurrent with the interior launch (events order the two): same lattice as the undivided run.
+    Copy transport with two slabs, and the RCCL transport on a ring of one rank."""
+    L = gpu
+    nx, ny = 2048, 4096
+    rng = np.random.default_rng(2048)
+    p = L.Param(nx, ny, 20, 10, 0.1, 0.01, 1.85)
+    ob = (rng.random((ny, nx)) < 0.02).astype(np.int32)
+    ob[0, :] = 1
+    with L.Lattice(p, ob) as lat:
+        av1 = np.concatenate([lat.run(12), lat.run(7)])
+        f1 = lat.final_state()
+    with L.Lattice(p, ob, nslabs=2, devices=[0, 0], exchange=L.EXCHANGE_COPY) as lat:
+        assert lat.info("time_block_active") == 2
+        av2 = np.concatenate([lat.run(12), lat.run(7)])
+        f2 = lat.final_state()
+    assert np.array_equal(f1.view(np.uint32), f2.view(np.uint32))
+    assert np.allclose(av1, av2, rtol=2e-6, atol=0)
+    os.environ["LBM_FORCE_EXCHANGE"] = "1"
+    try:
+        for tb in (2, 1):
+            with L.Lattice(p, ob, rank=0, nranks=1, device=0, unique_id=L.rccl_unique_id(), exchange=L.EXCHANGE_RCCL) as lat:
+                lat.set_option("time_block", tb)
+                av3 = np.concatenate([lat.run(12), lat.run(7)])
+                f3 = lat.final_state()
+            assert np.array_equal(f1.view(np.uint32), f3.view(np.uint32)), tb
+            assert np.allclose(av1, av3, rtol=2e-6, atol=0)
+    finally:
+        del os.environ["LBM_FORCE_EXCHANGE"]
