@@ -167,6 +167,7 @@ def measure(name, world, rank, local_rank, steps, warmup):
     exchange, halo_note = choose_exchange(p, ob, world, rank, local_rank)
     lat = make_lattice(p, ob, world, rank, local_rank, exchange)
     r0, r1 = lat.slab_rows(0)
+    mass0 = lat.total_density()          # global (all-reduced) in every mode
     if warmup > 0:
         lat.run(warmup)
 
@@ -187,6 +188,10 @@ def measure(name, world, rank, local_rank, steps, warmup):
         dt, gpu_ms = t[0].item(), t[1].item()
     vw = int(lat.info("vector_width"))
     tb = int(lat.info("time_block_active"))              # 2: two steps per launch (lbm_sweep2)
+    # stale or missing halos would break the mass balance at the slab boundaries long before anything
+    # goes non-finite; float32 rounding alone drifts ~1e-8 per step (tests/test_gpu_parity.py)
+    mass_drift = abs(lat.total_density() - mass0) / mass0
+    fence()
     lat.close()
     cells = p.nx * p.ny
     local_cells = p.nx * (r1 - r0)
@@ -211,7 +216,7 @@ def measure(name, world, rank, local_rank, steps, warmup):
                      "traffic_gbs": None if traffic is None else round(traffic / launch_s / 1e9, 1),
                      "traffic_frac_of_peak": None if traffic is None else round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4)},
         "data": data, "params": p, "blocked": int(ob.sum()), "av_last": float(av[-1]), "finite": bool(np.isfinite(av).all()),
-        "halo": halo_note,
+        "halo": halo_note, "mass_drift": mass_drift,
     }
 
 
@@ -340,6 +345,8 @@ def main():
             "cpu_baseline": cpu,
             "hbm_frac_of_peak_whole_job": round(head["mlups"] * BYTES_PER_LUP / 1e3 / (HBM_PEAK_GBS * world), 4),
             "results_finite": head["finite"],
+            "mass_drift": float("%.3g" % head["mass_drift"]),
+            "results_valid": bool(head["finite"] and head["mass_drift"] < 1e-6 * (args.steps + args.warmup) + 1e-5),
         }
         if also is not None:
             line["also"] = {args.also: {
