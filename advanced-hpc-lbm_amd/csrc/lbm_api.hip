@@ -3,15 +3,21 @@
 // Host-side structure (MI355X-first, nothing here mirrors the reference's
 // serial layout):
 //   * a context owns one or more ROW SLABS; each slab lives on one GPU with
-//     both lattices resident in HBM as 9 SoA planes, a byte mask, two small
-//     halo receive buffers and two packed halo send buffers per parity;
-//   * per step and slab: a boundary launch (first and last local row) that also
-//     packs the halo rows, then the halo exchange on a second stream
-//     (RCCL send/recv over xGMI, or peer copies inside one process) which
-//     overlaps the interior launch on the compute stream; events join them;
+//     both lattices resident in HBM as 9 SoA planes, a byte mask and nine-slot
+//     halo buffers per launch parity;
+//   * a launch group advances the lattice by two steps (lbm_sweep2, wherever
+//     the lattice tiles) or by one (lbm_sweep);
+//   * slabs with neighbours trade halos once per launch group, by one of three
+//     transports: RCCL send/recv on a second stream between an edge launch and
+//     the interior launch it overlaps (events join the streams); peer copies
+//     inside one process; or peer-to-peer -- the edge tiles of ONE launch per
+//     group store straight into the neighbour's halo block over xGMI and hand
+//     off through flags polled in-kernel (run_p2p: no events, no host-side
+//     exchange, no collective in the loop);
 //   * no host synchronisation inside the step loop; per-step speed sums stay
-//     on the device (one double per step and slab) and are reduced once at
-//     the end of the run.
+//     on the device (one double per step and slab, folded from per-block
+//     partials by block 0 of the NEXT launch) and are reduced once at the end
+//     of the run.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <stdarg.h>

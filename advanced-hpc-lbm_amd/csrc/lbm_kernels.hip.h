@@ -14,10 +14,18 @@
 //                part 1b); a one-row prologue kernel covers the first step and
 //                the last step of a run leaves the lattice unbiased.
 //
-// Data layout in HBM (per slab of nyl rows): 9 planes of nyl x pitch floats,
-// plane k = distribution k, x fastest; one byte per cell for the blocked map.
-// A thread owns V consecutive cells of one row, so the unshifted planes move as
-// one 16-byte access per lane (V = 4) and a wave covers 1 KiB per plane and row.
+// Data layout in HBM (per slab of nyl rows): 9 planes of nyl x pitch floats
+// (+ padding on the plane stride), plane k = distribution k, x fastest; one
+// byte per cell for the blocked map.
+//
+// Kernels in this file:
+//   lbm_sweep<V, MODE>          one step per pass; a thread owns V consecutive cells of a row
+//   lbm_sweep2<TX, TY, MODE, KIND, NT, PARTIAL>
+//                               two steps per pass through LDS (default where it applies);
+//                               KIND = plain / slab edge / whole slab with in-kernel
+//                               peer-to-peer halo hand-off
+//   lbm_p2p_push                halo wait / push outside the fused launch (peer-to-peer)
+//   small ones: accelerate row, halo packing, partial-sum folds, layout conversion, derived fields
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
