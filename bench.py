@@ -110,12 +110,12 @@ def choose_exchange(p, ob, world, rank, local_rank):
         av_true = np.concatenate([whole.run(6), whole.run(3)])
         rb, re_ = L.slab_bounds(p.ny, world, rank)
         st_true = whole.read_state()[rb:re_].copy()
-    results, speed, note = {}, {}, ""
     probe_steps = 400 if p.nx * p.ny <= (1 << 22) else 40
-    for mode in (L.EXCHANGE_RCCL, L.EXCHANGE_P2P):
-        # every rank walks through the same collectives whatever happens to it: library calls sit in
-        # try blocks, the agreement all-reduces between them
-        ok, st, av, lat = True, None, None, None
+
+    def probe(mode):
+        """(ok, note, seconds for probe_steps).  Every rank walks through the same collectives whatever
+        happens to it: library calls sit in try blocks, the agreement all-reduces between them."""
+        ok, note, secs, lat = True, "", None, None
         try:
             lat = make_lattice(p, ob, world, rank, local_rank, mode)
             if mode == L.EXCHANGE_P2P and int(lat.info("exchange")) != L.EXCHANGE_P2P:
@@ -144,7 +144,7 @@ def choose_exchange(p, ob, world, rank, local_rank):
             dist.barrier()
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            speed[mode] = t.item()
+            secs = t.item()
             ok = all_ranks_agree(ok, world)
         dist.barrier()
         try:
@@ -152,21 +152,30 @@ def choose_exchange(p, ob, world, rank, local_rank):
                 lat.close()
         except Exception:
             pass
-        lat = None
-        if not ok:
-            if mode == L.EXCHANGE_RCCL:
-                raise SystemExit(f"RCCL halo exchange failed its check against the undivided lattice: {note}")
-            return L.EXCHANGE_RCCL, "RCCL send/recv (peer-to-peer self-check could not run: %s)" % (note or "failure on another rank")
-        results[mode] = (st, av)
-    same = True   # both transports reproduced the undivided lattice bit for bit on every rank
-    if all_ranks_agree(same, world) and speed[L.EXCHANGE_P2P] > 1.05 * speed[L.EXCHANGE_RCCL]:
-        return L.EXCHANGE_RCCL, ("RCCL send/recv, 9*nx floats per direction per pair of steps (peer-to-peer halos passed the "
-                                 "self-check but were slower here: %.1f vs %.1f ms per %d steps)"
-                                 % (speed[L.EXCHANGE_P2P] * 1e3, speed[L.EXCHANGE_RCCL] * 1e3, probe_steps))
-    if all_ranks_agree(same, world):
-        return L.EXCHANGE_P2P, ("peer-to-peer: edge tiles store 9*nx floats per direction per PAIR of steps straight into the "
-                                "neighbour's halo block over xGMI, in-kernel flags (self-check at start-up on this machine: bit-identical to the undivided lattice, as is RCCL send/recv)")
-    return L.EXCHANGE_RCCL, "RCCL send/recv (peer-to-peer self-check MISMATCHED -- not used)"
+        return ok, note, secs
+
+    ok_r, note_r, secs_r = probe(L.EXCHANGE_RCCL)
+    extra = ""
+    if not ok_r:
+        # last resort: one step per launch, one-row halos (the simplest protocol)
+        os.environ["LBM_TIME_BLOCK"] = "1"
+        with L.Lattice(p, ob, nslabs=1, devices=[local_rank]) as whole:
+            av_true = np.concatenate([whole.run(6), whole.run(3)])
+            st_true = whole.read_state()[rb:re_].copy()
+        ok_r2, note_r2, secs_r = probe(L.EXCHANGE_RCCL)
+        if not ok_r2:
+            raise SystemExit(f"halo exchange failed its check against the undivided lattice: {note_r}; one step per launch: {note_r2}")
+        extra = f" [two-step halos failed the check ({note_r}): one step per launch]"
+    ok_p, note_p, secs_p = probe(L.EXCHANGE_P2P)
+    if not ok_p:
+        return L.EXCHANGE_RCCL, "RCCL send/recv (peer-to-peer halos not usable here: %s)%s" % (note_p or "failure on another rank", extra)
+    if secs_p > 1.05 * secs_r:
+        return L.EXCHANGE_RCCL, ("RCCL send/recv (peer-to-peer halos passed the check against the undivided lattice but were "
+                                 "slower here: %.1f vs %.1f ms per %d steps)%s" % (secs_p * 1e3, secs_r * 1e3, probe_steps, extra))
+    return L.EXCHANGE_P2P, ("peer-to-peer: edge tiles store their halo rows (9*nx floats per direction per pair of steps) straight "
+                            "into the neighbour's halo block over xGMI, in-kernel flags; checked at start-up on this machine: "
+                            "bit-identical to the undivided lattice, as is RCCL send/recv; %.1f vs %.1f ms per %d steps%s"
+                            % (secs_p * 1e3, secs_r * 1e3, probe_steps, extra))
 
 
 def measure(name, world, rank, local_rank, steps, warmup):
