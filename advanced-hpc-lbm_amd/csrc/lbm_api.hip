@@ -133,7 +133,9 @@ struct Slab {
   float* partials[2] = {nullptr, nullptr};
   int partial_cap = 0;
   double* sums = nullptr;      // one double per step of the current run
+  double* sums_host = nullptr; // pinned staging for the same (one async copy at the end of a run)
   int sums_cap = 0;
+  uint32_t* err_host = nullptr;  // pinned: copy of the peer-to-peer error word, fetched with the sums
   double* scratch_d = nullptr; // small double scratch (derive / reductions)
   int scratch_cap = 0;
   // sc: interior launches (and everything outside the step loop); se: edge launches, higher
@@ -171,6 +173,7 @@ struct lbm_ctx {
   uint32_t seq = 0;            // peer-to-peer: sequence number of the last launch group (same on all slabs)
   bool p2p_connected = false;
   bool no_comm = false;        // rank mode without RCCL: results are this rank's contribution
+  bool p2p_failed = false;     // a peer-to-peer halo wait timed out: the lattice is no longer defined
   double gpu_ms = 0.0, wall_ms = 0.0;
 };
 
@@ -219,9 +222,10 @@ int slab_alloc_halos(lbm_ctx* c, Slab& s) {
     HIPC(hipMalloc((void**)&s.blocked_gn, (size_t)nx));
     s.halo_bytes = (sizeof(float) * lbm::kHaloSlots * (size_t)nx + 255) / 256 * 256;
     const size_t total = 4 * s.halo_bytes + 512;
-    // uncached: the neighbours write it over xGMI behind this GPU's L2
+    // uncached: the neighbours write it over xGMI behind this GPU's L2.  Fine-grained memory is NOT
+    // accepted as a substitute (the local L2 may keep ghost rows a neighbour has since rewritten):
+    // without uncached memory peer-to-peer halos count as unavailable and the caller uses RCCL.
     hipError_t e = hipExtMallocWithFlags((void**)&s.comm_block, total, hipDeviceMallocUncached);
-    if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags((void**)&s.comm_block, total, hipDeviceMallocFinegrained); }
     if (e != hipSuccess) { (void)hipGetLastError(); s.comm_block = nullptr; return fail(LBM_EHIP, "cannot allocate uncached halo memory: %s", hipGetErrorString(e)); }
     HIPC(hipMemset(s.comm_block, 0, total));
     HIPC(hipMalloc((void**)&s.counters, 64 * sizeof(uint32_t)));
@@ -442,6 +446,8 @@ void slab_free(Slab& s) {
   }
   if (s.blocked) (void)hipFree(s.blocked);
   if (s.sums) (void)hipFree(s.sums);
+  if (s.sums_host) (void)hipHostFree(s.sums_host);
+  if (s.err_host) (void)hipHostFree(s.err_host);
   if (s.scratch_d) (void)hipFree(s.scratch_d);
   if (s.ev_t0) (void)hipEventDestroy(s.ev_t0);
   if (s.ev_t1) (void)hipEventDestroy(s.ev_t1);
@@ -543,13 +549,21 @@ int exchange_halos(lbm_ctx* c, int q, int slot0, int nslots) {
   return LBM_OK;
 }
 
+// Per-step sums of a run: device array + pinned host staging.  Sized once at lbm_create for the
+// deck's own maxIters and grown geometrically, so that a run never allocates unless it is longer
+// than anything before it (an allocation inside lbm_run costs more than a 20-step run of 1024^2).
 int ensure_sums(Slab& s, int nsteps) {
   if (s.sums_cap >= nsteps) return LBM_OK;
   HIPC(hipSetDevice(s.dev));
+  int cap = std::max(1024, s.sums_cap);
+  while (cap < nsteps) cap = (cap > (1 << 29)) ? nsteps : cap * 2;
   if (s.sums) HIPC(hipFree(s.sums));
-  s.sums = nullptr;
-  HIPC(hipMalloc((void**)&s.sums, sizeof(double) * nsteps));
-  s.sums_cap = nsteps;
+  if (s.sums_host) HIPC(hipHostFree(s.sums_host));
+  s.sums = nullptr; s.sums_host = nullptr; s.sums_cap = 0;
+  HIPC(hipMalloc((void**)&s.sums, sizeof(double) * cap));
+  HIPC(hipHostMalloc((void**)&s.sums_host, sizeof(double) * cap, hipHostMallocDefault));
+  if (!s.err_host) { HIPC(hipHostMalloc((void**)&s.err_host, 64, hipHostMallocDefault)); *s.err_host = 0; }
+  s.sums_cap = cap;
   return LBM_OK;
 }
 
@@ -561,6 +575,8 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
     int rc = slab_alloc(c, s, exchanging);
     if (rc) return rc;
     rc = slab_upload(c, s, obstacles, cells);
+    if (rc) return rc;
+    rc = ensure_sums(s, std::max(c->p.maxIters, 1));
     if (rc) return rc;
   }
   pick_defaults(c);
@@ -678,8 +694,17 @@ extern "C" int lbm_create(const lbm_param* params, const int* obstacles, const f
   const char* force = getenv("LBM_FORCE_EXCHANGE");
   if (nslabs == 1 && !(force && atoi(force)))
     c->exchange = 0;
-  else
-    c->exchange = (exchange == LBM_EXCHANGE_AUTO) ? LBM_EXCHANGE_RCCL : exchange;
+  else if (exchange == LBM_EXCHANGE_AUTO) {
+    // RCCL wants one rank per device (ncclCommInitAll rejects a repeated device): several slabs
+    // on one GPU trade their halos with peer copies instead
+    bool repeated = false;
+    for (int i = 0; i < nslabs && !repeated; ++i)
+      for (int j = 0; j < i; ++j)
+        if ((devices ? devices[i] : i) == (devices ? devices[j] : j)) { repeated = true; break; }
+    c->exchange = repeated ? LBM_EXCHANGE_COPY : LBM_EXCHANGE_RCCL;
+  } else {
+    c->exchange = exchange;
+  }
   if (c->exchange == LBM_EXCHANGE_P2P && params->ny / nslabs < 2) {
     delete c;
     return fail(LBM_EINVAL, "peer-to-peer halos need at least 2 rows per slab");
@@ -755,11 +780,8 @@ extern "C" int lbm_create_rank_ex(const lbm_param* params, const int* obstacles,
     void* probe = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipExtMallocWithFlags(&probe, 4096, hipDeviceMallocUncached) != hipSuccess) {
       (void)hipGetLastError();
-      if (hipExtMallocWithFlags(&probe, 4096, hipDeviceMallocFinegrained) != hipSuccess) {
-        (void)hipGetLastError();
-        p2p_rc = fail(LBM_EHIP, "uncached / fine-grained device memory not available");
-        c->exchange = LBM_EXCHANGE_RCCL;
-      }
+      p2p_rc = fail(LBM_EHIP, "uncached device memory not available");
+      c->exchange = LBM_EXCHANGE_RCCL;
     }
     if (probe) (void)hipFree(probe);
   }
@@ -1006,36 +1028,47 @@ int launch_pair(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev, floa
 
 namespace {
 
-// End of a run: reduce across ranks (if there is a communicator), wait, fetch the per-step sums.
+// End of a run: reduce across ranks (if there is a communicator), fetch the per-step sums and the
+// peer-to-peer error word through pinned staging with async copies queued behind the step loop,
+// then ONE wait per slab (s.sc has joined the edge and exchange streams by then).
 int collect_sums(lbm_ctx* c, int nsteps, float* av_vels, std::chrono::steady_clock::time_point wall0) {
   if (c->rank_mode && c->slabs[0].comm != nullptr) {   // (a ring of one rank has a communicator too: identity)
     Slab& s = c->slabs[0];
     NCCLC(rccl::AllReduce(s.sums, s.sums, (size_t)nsteps, rccl::kFloat64, rccl::kSum, s.comm, s.sc));
   }
-  std::vector<double> acc(nsteps, 0.0), tmp(nsteps);
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    if (av_vels) HIPC(hipMemcpyAsync(s.sums_host, s.sums, sizeof(double) * nsteps, hipMemcpyDeviceToHost, s.sc));
+    if (s.counters) HIPC(hipMemcpyAsync(s.err_host, s.counters + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, s.sc));
+  }
   double gpu_ms = 0.0;
   for (auto& s : c->slabs) {
     HIPC(hipSetDevice(s.dev));
-    HIPC(hipStreamSynchronize(s.sx));
-    HIPC(hipStreamSynchronize(s.se));
+    if (c->exchange != 0) {
+      HIPC(hipStreamSynchronize(s.sx));
+      HIPC(hipStreamSynchronize(s.se));
+    }
     HIPC(hipStreamSynchronize(s.sc));
     float ms = 0.f;
     HIPC(hipEventElapsedTime(&ms, s.ev_t0, s.ev_t1));
     if (ms > gpu_ms) gpu_ms = ms;
-    if (s.counters) {
-      uint32_t err = 0;
-      HIPC(hipMemcpy(&err, s.counters + 32, sizeof(err), hipMemcpyDeviceToHost));
-      if (err) return fail(LBM_EHIP, "peer-to-peer halo wait timed out (a neighbouring slab stopped)");
-    }
-    if (av_vels) {
-      HIPC(hipMemcpy(tmp.data(), s.sums, sizeof(double) * nsteps, hipMemcpyDeviceToHost));
-      for (int i = 0; i < nsteps; ++i) acc[i] += tmp[i];
-    }
   }
   c->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
   c->gpu_ms = gpu_ms;
-  if (av_vels)
-    for (int i = 0; i < nsteps; ++i) av_vels[i] = (float)(acc[i] / (double)c->tot_fluid);  // d2q9-bgk.c:1811
+  for (auto& s : c->slabs)
+    if (s.counters && *s.err_host) {
+      c->p2p_failed = true;
+      return fail(LBM_EHIP, "peer-to-peer halo wait timed out (a neighbouring slab stopped)");
+    }
+  if (av_vels) {
+    const double nf = (double)c->tot_fluid;
+    const size_t ns = c->slabs.size();
+    for (int i = 0; i < nsteps; ++i) {
+      double acc = 0.0;
+      for (size_t k = 0; k < ns; ++k) acc += c->slabs[k].sums_host[i];
+      av_vels[i] = (float)(acc / nf);  // d2q9-bgk.c:1811
+    }
+  }
   return LBM_OK;
 }
 
@@ -1130,8 +1163,7 @@ int run_p2p(lbm_ctx* c, int nsteps, float* av_vels) {
     for (auto& s : c->slabs) {
       HIPC(hipSetDevice(s.dev));
       const int nbtot = ntx * (s.nyl / kT2Y);
-      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql], nbtot, s.sums + (tt - 2));
-      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql] + nbtot, nbtot, s.sums + (tt - 1));
+      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(2), dim3(lbm::kBlock), 0, s.sc, s.partials[ql], nbtot, s.sums + (tt - 2), nbtot);
       HIPC(hipGetLastError());
     }
   }
@@ -1171,7 +1203,7 @@ int run_p2p(lbm_ctx* c, int nsteps, float* av_vels) {
     HIPC(hipSetDevice(s.dev));
     if (first_single < nsteps) {
       hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql],
-                         sweep_blocks(c, s.nyl), s.sums + (nsteps - 1));
+                         sweep_blocks(c, s.nyl), s.sums + (nsteps - 1), 0);
       HIPC(hipGetLastError());
     }
     HIPC(hipEventRecord(s.ev_t1, s.sc));
@@ -1185,6 +1217,7 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
   if (!c) return fail(LBM_EINVAL, "ctx is NULL");
   if (nsteps < 0) return fail(LBM_EINVAL, "nsteps < 0");
   if (nsteps == 0) { c->gpu_ms = c->wall_ms = 0.0; return LBM_OK; }
+  if (c->p2p_failed) return fail(LBM_EHIP, "a peer-to-peer halo wait timed out earlier: this lattice is no longer defined");
   const int nx = c->p.nx;
   const float a1 = c->p.density * c->p.accel / 9.f;   // d2q9-bgk.c:230-231
   const float a2 = c->p.density * c->p.accel / 36.f;
@@ -1237,8 +1270,7 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
       HIPC(hipSetDevice(s.dev));
       if (ex && split_edge_stream(c, s)) HIPC(hipStreamWaitEvent(s.sc, s.ev_bnd[ql], 0));   // join the edge stream
       const int nbtot = cdiv(nx, kT2X) * cdiv(s.nyl, kT2Y);
-      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql], nbtot, s.sums + (tt - 2));
-      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql] + nbtot, nbtot, s.sums + (tt - 1));
+      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(2), dim3(lbm::kBlock), 0, s.sc, s.partials[ql], nbtot, s.sums + (tt - 2), nbtot);
       HIPC(hipGetLastError());
     }
   }
@@ -1253,7 +1285,7 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
     if (ex && split_edge_stream(c, s)) HIPC(hipStreamWaitEvent(s.sc, s.ev_bnd[ql], 0));     // join the edge stream
     if (first_single < nsteps) {
       hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, s.partials[ql],
-                         single_partial_count(c, s), s.sums + (nsteps - 1));
+                         single_partial_count(c, s), s.sums + (nsteps - 1), 0);
       HIPC(hipGetLastError());
     }
     HIPC(hipEventRecord(s.ev_t1, s.sc));
@@ -1305,7 +1337,7 @@ static int derive_all(lbm_ctx* c, float* out4, double* speed_sum, double* mass) 
     hipLaunchKernelGGL(lbm::lbm_derive, dim3(grid), dim3(lbm::kBlock), 0, s.sc, s.lat[c->cur], s.plane, s.pitch, nx, ncell,
                        s.blocked, c->p.density, d_out, part, mpart);
     HIPC(hipGetLastError());
-    hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, part, grid, res);
+    hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(1), dim3(lbm::kBlock), 0, s.sc, part, grid, res, 0);
     hipLaunchKernelGGL(lbm::lbm_fold_double, dim3(1), dim3(lbm::kBlock), 0, s.sc, mpart, grid, res + 1);
     HIPC(hipGetLastError());
     if (c->rank_mode && s.comm != nullptr)

@@ -403,6 +403,10 @@ constexpr int kNoRow = -100;   // "no accelerate row on this slab"
 // Waiting before writing is what makes two buffers enough: the neighbour's flag seq-1 is only
 // raised after all its edge blocks of launch seq-1 -- the last readers of the buffer this launch
 // overwrites -- have finished.  Every spin is bounded (wall clock); a timeout raises *err.
+// A halo wait gives up after this long (wall clock, 100 MHz ticks): 4 s.  It is also the largest skew
+// between two neighbouring ranks' lbm_run calls that the peer-to-peer transport tolerates.
+constexpr long long kP2PTimeoutTicks = 400000000LL;
+
 struct P2PSync {
   const uint32_t* flag_s;      // written by the south neighbour: "pushed seq X into your ghost_s"
   const uint32_t* flag_n;      // written by the north neighbour
@@ -416,12 +420,18 @@ struct P2PSync {
 };
 
 __device__ __forceinline__ void p2p_wait(const uint32_t* flag, uint32_t want, uint32_t* err) {
-  const long long t0 = wall_clock64();   // 100 MHz
-  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-    __builtin_amdgcn_s_sleep(8);
-    if (wall_clock64() - t0 > 400000000LL) {   // 4 s: the neighbour is gone
-      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      break;
+  // *err is sticky: once any wait of this slab has timed out, every later wait -- in this launch and in
+  // all the launches already queued behind it -- returns at once, so the queue drains in microseconds
+  // instead of holding the GPU for 4 s per launch and side.
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+    const long long t0 = wall_clock64();   // 100 MHz
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > kP2PTimeoutTicks ||
+          __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the neighbour is gone
+        break;
+      }
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);   // system scope: invalidates this CU's L1 ...
@@ -830,13 +840,15 @@ __global__ void lbm_pack_halos9(const float* lat, long plane, int pitch, int nx,
   }
 }
 
-// Folds a step's block partials into its slab sum (after the last step of a run).
-__global__ __launch_bounds__(kBlock) void lbm_fold_partials(const float* partials, int count, double* out) {
+// Folds block partials into slab sums (after the last step of a run): block b folds the `count`
+// floats at partials + b*stride into out[b] -- both steps of a final pair in one launch.
+__global__ __launch_bounds__(kBlock) void lbm_fold_partials(const float* partials, int count, double* out, int stride) {
   __shared__ double red_d[kBlock / 64];
+  const float* p = partials + (long)blockIdx.x * stride;
   double s = 0.0;
-  for (int i = threadIdx.x; i < count; i += kBlock) s += (double)partials[i];
+  for (int i = threadIdx.x; i < count; i += kBlock) s += (double)p[i];
   s = block_sum<double>(s, red_d);
-  if (threadIdx.x == 0) *out = s;
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
 // Accelerate phase on one row of a resident lattice (first step of a run).

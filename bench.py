@@ -42,18 +42,15 @@ BYTES_PER_LUP = 72.0     # 9 float32 reads + 9 float32 writes
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def wall_x(n: int) -> int:
-    return 2730 if n == 8192 else (341 * n) // 1024
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from make_deck import obstacle_map, wall_x  # noqa: E402  (the generator of the synthetic decks the CLI reads)
 
 
 def synthetic_obstacles(n: int) -> np.ndarray:
     """BASELINE.json's synthetic deck: the 1024x1024 geometry scaled by n/1024 -- closed box
-    plus a full-height wall at x = n/3 (2730 for 8192)."""
-    ob = np.zeros((n, n), dtype=np.int32)
-    ob[0, :] = ob[-1, :] = 1
-    ob[:, 0] = ob[:, -1] = 1
-    ob[:, wall_x(n)] = 1
-    return ob
+    plus a full-height wall at x = n/3 (2730 for 8192); tools/make_deck.py writes the same map
+    as the params + obstacle files the CLI reads."""
+    return obstacle_map(n, n)
 
 
 def make_workload(name: str):

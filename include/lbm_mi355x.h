@@ -57,13 +57,20 @@ typedef struct {
 typedef struct lbm_ctx lbm_ctx;
 
 /* How neighbouring row slabs trade their one-row halos each step. */
-#define LBM_EXCHANGE_AUTO   0  /* 1 slab: none (periodic self-wrap); >1 slabs: RCCL */
+#define LBM_EXCHANGE_AUTO   0  /* 1 slab: none (periodic self-wrap); >1 slabs: RCCL, or peer
+                                  copies when the device list repeats a device (RCCL wants
+                                  one rank per GPU) */
 #define LBM_EXCHANGE_COPY   1  /* hipMemcpyAsync between slabs of ONE process (peer copies) */
 #define LBM_EXCHANGE_RCCL   2  /* ncclSend/ncclRecv pairs over xGMI, own stream, overlapped */
 #define LBM_EXCHANGE_P2P    3  /* kernels store their halo rows straight into the neighbour's
                                   buffers over xGMI and hand off through flags (no host, no
                                   collective call in the step loop); needs peer access (one
-                                  process) or hipIpc (one process per GPU) */
+                                  process) or hipIpc (one process per GPU) and uncached device
+                                  memory.  A halo wait gives up after 4 s: ranks must enter
+                                  lbm_run within 4 s of each other, and when a neighbour stops,
+                                  lbm_run returns LBM_EHIP within seconds (every queued launch
+                                  sees the sticky error word and drains); the lattice is then
+                                  undefined and later lbm_run calls on the context fail */
 
 /* Message of the last failure on this thread ("" if none). */
 const char* lbm_last_error(void);

@@ -91,16 +91,21 @@ def test_fifty_steps_against_float_oracle(gpu, O, oracle, deck):
     av_o = oracle.run(op, cells, ob, 50)
     # every cells-per-thread width x kernel flavour: 0 = IEEE divide/sqrt, 1 = v_rcp/v_sqrt,
     # 7 = that + nontemporal loads and stores (the flavours the library picks by lattice size)
-    for V, variant in ((4, 0), (4, 1), (4, 7), (2, 0), (2, 1), (2, 7), (1, 1), (1, 6)):
+    # (time_block 1 = the one-step kernel lbm_sweep<V>, which is what V selects; 2 = lbm_sweep2, where
+    # the flavour bits still apply)
+    combos = [(1, V, variant) for V in (4, 2, 1) for variant in (0, 1, 6, 7)] + [(2, 4, 0), (2, 4, 1), (2, 4, 3)]
+    for tb, V, variant in combos:
         with L.Lattice(p, ob) as lat:
+            lat.set_option("time_block", tb)
             lat.set_option("vector_width", V)
             lat.set_option("kernel_variant", variant)
             assert lat.info("vector_width") == V and lat.info("kernel_variant") == variant
+            assert lat.info("time_block_active") == tb
             av = lat.run(50)
             st = lat.read_state()
             fs = lat.final_state()
-        assert np.abs(st - cells).max() <= 5e-5 * np.abs(cells).max(), (V, variant)
-        assert np.allclose(av, av_o, rtol=1e-4, atol=0), (V, variant)
+        assert np.abs(st - cells).max() <= 5e-5 * np.abs(cells).max(), (tb, V, variant)
+        assert np.allclose(av, av_o, rtol=1e-4, atol=0), (tb, V, variant)
         fo = oracle.final_state(op, cells, ob)
         assert np.allclose(fs[..., 3], fo[..., 3], rtol=1e-5, atol=0)           # pressure
         assert np.allclose(fs[..., :3], fo[..., :3], rtol=0, atol=2e-4 * np.abs(fo[..., 2]).max())
@@ -361,6 +366,29 @@ def test_rccl_transport_single_rank_ring(gpu):
     for av, st in ((av2, st2), (av3, st3), (av4, st4)):
         assert np.array_equal(st1.view(np.uint32), st.view(np.uint32))
         assert np.allclose(av1, av, rtol=2e-6, atol=0)
+
+
+def test_rccl_transport_single_rank_ring_1024_two_step_halos(gpu):
+    """The shipped 1024x1024 deck through the RCCL send/recv transport with nine-slot halos once per
+    pair of steps (the form an N-GPU run of this deck uses), ring of one rank, against the undivided
+    lattice: bit-identical state, av_vels within summation order."""
+    L = gpu
+    pf, of = deck_paths("1024x1024")
+    p = L.read_params(pf)
+    ob = L.read_obstacles(of, p)
+    with L.Lattice(p, ob) as lat:
+        av1 = np.concatenate([lat.run(60), lat.run(21)])
+        st1 = lat.read_state()
+    os.environ["LBM_FORCE_EXCHANGE"] = "1"
+    try:
+        with L.Lattice(p, ob, rank=0, nranks=1, device=0, unique_id=L.rccl_unique_id(), exchange=L.EXCHANGE_RCCL) as lat:
+            assert lat.info("exchange") == L.EXCHANGE_RCCL and lat.info("time_block_active") == 2
+            av2 = np.concatenate([lat.run(60), lat.run(21)])
+            st2 = lat.read_state()
+    finally:
+        del os.environ["LBM_FORCE_EXCHANGE"]
+    assert np.array_equal(st1.view(np.uint32), st2.view(np.uint32))
+    assert np.allclose(av1, av2, rtol=2e-6, atol=0)
 
 
 def test_derived_quantities_match_oracle_on_resident_state(gpu, O, oracle):
@@ -691,3 +719,85 @@ def test_big_slabs_run_edges_on_their_own_stream(gpu):
             assert np.allclose(av1, av3, rtol=2e-6, atol=0)
     finally:
         del os.environ["LBM_FORCE_EXCHANGE"]
+
+
+def _p2p_silent_neighbour_worker(rank, deck, conn):
+    """Rank 0 runs; rank 1 maps everything and then never launches a step."""
+    import sys
+    import time
+    for p_ in (ROOT, os.path.join(ROOT, "oracle")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    import advanced_hpc_lbm_amd as L
+    pf, of = deck
+    p = L.read_params(pf)
+    ob = L.read_obstacles(of, p)
+    lat = L.Lattice(p, ob, rank=rank, nranks=2, device=0, unique_id=None, exchange=L.EXCHANGE_P2P)
+    conn.send(lat.p2p_handle())
+    lat.p2p_connect(conn.recv())
+    if rank == 0:
+        t0 = time.perf_counter()
+        try:
+            lat.run(2000)        # 1000 queued launches: without the sticky error word, 4 s each
+            conn.send(("no error", time.perf_counter() - t0))
+        except L.LbmError as e:
+            dt = time.perf_counter() - t0
+            try:
+                lat.run(2)
+                again = "second run accepted"
+            except L.LbmError as e2:
+                again = str(e2)
+            conn.send((str(e), dt, again))
+    conn.recv()          # keep the halo block mapped until the parent says so
+    lat.close()
+
+
+def test_peer_to_peer_halo_wait_times_out_quickly(gpu):
+    """A rank whose neighbour never runs: the first halo wait gives up after 4 s, raises the sticky
+    error word, every launch queued behind it drains at once, and lbm_run returns LBM_EHIP within
+    seconds (not 4 s x launches x sides); the context refuses further runs."""
+    import multiprocessing as mp
+    L = gpu
+    deck = deck_paths("128x256")
+    ctx = mp.get_context("spawn")
+    pipes = [ctx.Pipe() for _ in range(2)]
+    procs = [ctx.Process(target=_p2p_silent_neighbour_worker, args=(r, deck, pipes[r][1])) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    try:
+        handles = []
+        for r in range(2):
+            assert pipes[r][0].poll(120), f"rank {r} did not come up"
+            handles.append(pipes[r][0].recv())
+        for r in range(2):
+            pipes[r][0].send(handles)
+        assert pipes[0][0].poll(60), "rank 0 still waiting: queued launches did not drain"
+        res = pipes[0][0].recv()
+        for r in range(2):
+            pipes[r][0].send("bye")
+    finally:
+        for pr in procs:
+            pr.join(60)
+            if pr.is_alive():
+                pr.kill()
+    assert len(res) == 3, res
+    msg, dt, again = res
+    assert "timed out" in msg and "[lbm error 3]" in msg, msg
+    assert 3.0 < dt < 15.0, dt
+    assert "no longer defined" in again, again
+
+
+def test_cli_row_partitioned_default_exchange_on_one_gpu(gpu, tmp_path):
+    """LBM_NGPUS=2 LBM_DEVICES=0,0 with the DEFAULT exchange: AUTO resolves to peer copies when the
+    device list repeats a device (RCCL wants one rank per GPU)."""
+    exe = os.path.join(ROOT, "d2q9-bgk")
+    pf, of = deck_paths("128x128")
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir()
+    two.mkdir()
+    r1 = subprocess.run([exe, pf, of], cwd=one, capture_output=True, text=True)
+    env = {k: v for k, v in os.environ.items() if k != "LBM_EXCHANGE"}
+    env.update(LBM_NGPUS="2", LBM_DEVICES="0,0")
+    r2 = subprocess.run([exe, pf, of], cwd=two, capture_output=True, text=True, env=env)
+    assert r1.returncode == 0 and r2.returncode == 0, r2.stderr
+    assert (one / "final_state.dat").read_bytes() == (two / "final_state.dat").read_bytes()
