@@ -32,6 +32,7 @@
 
 #include "../../include/lbm_mi355x.h"
 #include "lbm_kernels.hip.h"
+#include "lbm_resident.hip.h"
 
 // ----------------------------------------------------------------- errors
 static thread_local char g_err[1024] = "";
@@ -174,6 +175,20 @@ struct lbm_ctx {
   bool p2p_connected = false;
   bool no_comm = false;        // rank mode without RCCL: results are this rank's contribution
   bool p2p_failed = false;     // a peer-to-peer halo wait timed out: the lattice is no longer defined
+  // engine: which kernel family lbm_run uses for a lattice alone on its GPU
+  //   0 auto = whichever measured faster (today: the streaming kernels everywhere -- the resident
+  //   kernel is bit-identical but its per-step hand-off costs more than it saves),
+  //   1 streaming only (lbm_sweep2 / lbm_sweep), 2 resident (lbm_resident) or fail
+  int engine = 0;
+  int engine_last = 0;         // what the last lbm_run used: 1 streaming, 2 resident
+  struct { int tx = 0, ty = 0, v = 0, threads = 0, ntx = 0, nty = 0; } rplan;   // resident tiling (tx == 0: none)
+  unsigned long long* rmail = nullptr;   // resident mailboxes
+  float* rpartials = nullptr;  // [steps][tiles]
+  long rpartials_cap = 0;      // in steps
+  uint32_t* rabort = nullptr;  // device abort word of the resident kernel
+  uint32_t rtag = 1;           // next unused mailbox tag (0 = never written)
+  bool resident_broken = false;   // a resident run gave up on this device: stay with the streaming kernels
+  int ncu = 0;                 // CUs of slab 0's device
   double gpu_ms = 0.0, wall_ms = 0.0;
 };
 
@@ -567,6 +582,8 @@ int ensure_sums(Slab& s, int nsteps) {
   return LBM_OK;
 }
 
+bool plan_resident(lbm_ctx* c);   // resident engine, below
+
 int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
   const bool exchanging = c->exchange != 0;
   const int ay = c->p.ny - 2;  // the accelerate row of the global lattice (d2q9-bgk.c:240)
@@ -580,6 +597,14 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
     if (rc) return rc;
   }
   pick_defaults(c);
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->slabs[0].dev) == hipSuccess) c->ncu = prop.multiProcessorCount;
+    else (void)hipGetLastError();
+    const char* e = getenv("LBM_ENGINE");
+    if (e) c->engine = (atoi(e) >= 0 && atoi(e) <= 2) ? atoi(e) : 0;
+    if (!exchanging && c->slabs.size() == 1) plan_resident(c);
+  }
   return LBM_OK;
 }
 
@@ -1040,6 +1065,7 @@ int collect_sums(lbm_ctx* c, int nsteps, float* av_vels, std::chrono::steady_clo
     HIPC(hipSetDevice(s.dev));
     if (av_vels) HIPC(hipMemcpyAsync(s.sums_host, s.sums, sizeof(double) * nsteps, hipMemcpyDeviceToHost, s.sc));
     if (s.counters) HIPC(hipMemcpyAsync(s.err_host, s.counters + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, s.sc));
+    if (c->rabort && &s == &c->slabs[0]) HIPC(hipMemcpyAsync(s.err_host + 1, c->rabort, sizeof(uint32_t), hipMemcpyDeviceToHost, s.sc));
   }
   double gpu_ms = 0.0;
   for (auto& s : c->slabs) {
@@ -1069,6 +1095,142 @@ int collect_sums(lbm_ctx* c, int nsteps, float* av_vels, std::chrono::steady_clo
       av_vels[i] = (float)(acc / nf);  // d2q9-bgk.c:1811
     }
   }
+  return LBM_OK;
+}
+
+// ----------------------------------------------------------------- resident engine
+// Tile shapes lbm_resident accepts: tx = v * 2^m with at most 64 lanes per tile row, tx | nx,
+// ty | ny, tx * ty <= kResidentMaxCells, (tx / v) * ty threads (rounded up to whole waves) <= 1024,
+// and at most one tile per CU (every tile must be resident at once: grid <= CUs is what guarantees
+// it, cdna_hip_programming.md §1).
+bool resident_tile_ok(const lbm_ctx* c, int tx, int ty, int v) {
+  const int nx = c->p.nx, ny = c->p.ny;
+  if (!(v == 1 || v == 2 || v == 4) || tx < v || ty < 1 || tx % v) return false;
+  const int lanes = tx / v;
+  if (lanes > 64 || (lanes & (lanes - 1)) != 0) return false;
+  if (tx > nx || ty > ny || nx % tx || ny % ty) return false;
+  if ((long)tx * ty > lbm::kResidentMaxCells) return false;
+  if ((lanes * ty + 63) / 64 * 64 > 1024) return false;
+  return (long)(nx / tx) * (ny / ty) <= c->ncu;
+}
+
+void resident_set_plan(lbm_ctx* c, int tx, int ty, int v) {
+  c->rplan.tx = tx; c->rplan.ty = ty; c->rplan.v = v;
+  c->rplan.threads = ((tx / v) * ty + 63) / 64 * 64;
+  c->rplan.ntx = c->p.nx / tx; c->rplan.nty = c->p.ny / ty;
+}
+
+// Picks the tiling with the lowest estimated time per step (cycles per CU): arithmetic
+// (about 115 VALU instructions per cell; a SIMD retires one wave-instruction every 2 cycles, a
+// lone wave every 4), LDS traffic of the pull and push, and the hand-off with the neighbours
+// (about 1 us of latency plus a term in the tile's perimeter).
+bool plan_resident(lbm_ctx* c) {
+  c->rplan.tx = 0;
+  if (c->ncu < 1) return false;
+  double best = 1e30;
+  for (int v : {4, 2, 1})
+    for (int m = 0; m <= 6; ++m) {
+      const int tx = v << m;
+      for (int ty = 1; ty <= c->p.ny && (long)tx * ty <= lbm::kResidentMaxCells; ++ty) {
+        if (!resident_tile_ok(c, tx, ty, v)) continue;
+        const int waves = ((tx / v) * ty + 63) / 64, wps = (waves + 3) / 4;
+        const double valu = (double)wps * v * 115.0 * (wps == 1 ? 4.0 : 2.0);
+        const double lds = (double)waves * 9.0 * ((v == 4 ? 4.0 : 2.0) + (v == 4 ? 13.0 : v == 2 ? 6.0 : 4.0));
+        const double cost = std::max(valu, lds) + 2000.0 + 4.0 * (tx + ty);
+        if (cost < best) { best = cost; resident_set_plan(c, tx, ty, v); }
+      }
+    }
+  return c->rplan.tx > 0;
+}
+
+void resident_free(lbm_ctx* c) {
+  if (c->slabs.empty()) return;
+  (void)hipSetDevice(c->slabs[0].dev);
+  if (c->rmail) (void)hipFree(c->rmail);
+  if (c->rpartials) (void)hipFree(c->rpartials);
+  if (c->rabort) (void)hipFree(c->rabort);
+  c->rmail = nullptr; c->rpartials = nullptr; c->rabort = nullptr; c->rpartials_cap = 0;
+}
+
+template <int V>
+void launch_resident_v(const lbm_ctx* c, const lbm::ResidentArgs& a, int grid, int threads, hipStream_t st) {
+  const char* dbg = getenv("LBM_RESIDENT_DEBUG");   // timing experiments (wrong results): see lbm_resident.hip.h
+  if (dbg && atoi(dbg) == 1) { hipLaunchKernelGGL((lbm::lbm_resident<V, lbm::kFastMath | lbm::kResDebugNoWait>), dim3(grid), dim3(threads), 0, st, a); return; }
+  if (dbg && atoi(dbg) == 2) { hipLaunchKernelGGL((lbm::lbm_resident<V, lbm::kFastMath | lbm::kResDebugNoWait | lbm::kResDebugNoSend>), dim3(grid), dim3(threads), 0, st, a); return; }
+  if (c->variant & lbm::kFastMath) hipLaunchKernelGGL((lbm::lbm_resident<V, lbm::kFastMath>), dim3(grid), dim3(threads), 0, st, a);
+  else hipLaunchKernelGGL((lbm::lbm_resident<V, 0>), dim3(grid), dim3(threads), 0, st, a);
+}
+
+// The whole run in one launch (lbm_resident.hip.h).  *done = false with LBM_OK means the kernel
+// gave up (a tile never heard from a neighbour: not every tile was resident): the source lattice
+// is untouched and the caller repeats the run with the streaming kernels.
+int run_resident(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
+  *done = false;
+  Slab& s = c->slabs[0];
+  HIPC(hipSetDevice(s.dev));
+  const auto& r = c->rplan;
+  const int ntiles = r.ntx * r.nty;
+  const size_t mail_bytes = sizeof(unsigned long long) * (size_t)ntiles * 2 * 8 * (size_t)(r.tx + r.ty);
+  if (!c->rmail) {
+    HIPC(hipMalloc((void**)&c->rmail, mail_bytes));
+    HIPC(hipMemsetAsync(c->rmail, 0, mail_bytes, s.sc));
+    c->rtag = 1;
+    if (!c->rabort) {
+      HIPC(hipMalloc((void**)&c->rabort, 64));
+      HIPC(hipMemsetAsync(c->rabort, 0, 64, s.sc));
+    }
+  }
+  if ((unsigned long long)c->rtag + (unsigned long long)nsteps >= 0x7fffff00ull) {   // tags would wrap: start over
+    HIPC(hipMemsetAsync(c->rmail, 0, mail_bytes, s.sc));
+    c->rtag = 1;
+  }
+  if (c->rpartials_cap < nsteps) {
+    long cap = std::max(1024L, c->rpartials_cap);
+    while (cap < nsteps) cap *= 2;
+    if (c->rpartials) HIPC(hipFree(c->rpartials));
+    c->rpartials = nullptr; c->rpartials_cap = 0;
+    HIPC(hipMalloc((void**)&c->rpartials, sizeof(float) * (size_t)cap * ntiles));
+    c->rpartials_cap = cap;
+  }
+  int rc = ensure_sums(s, nsteps);
+  if (rc) return rc;
+
+  lbm::ResidentArgs a;
+  a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
+  a.plane = s.plane; a.pitch = s.pitch; a.nx = c->p.nx; a.ny = c->p.ny;
+  a.blocked = s.blocked; a.omega = c->p.omega;
+  a.accel_row = c->p.ny - 2;
+  a.a1 = c->p.density * c->p.accel / 9.f; a.a2 = c->p.density * c->p.accel / 36.f;
+  a.tx = r.tx; a.ty = r.ty; a.ntx = r.ntx; a.nty = r.nty;
+  a.nsteps = nsteps;
+  a.tag0 = c->rtag;
+  a.mail = c->rmail; a.partials = c->rpartials; a.abort_word = c->rabort;
+  c->rtag += (uint32_t)nsteps;
+
+  const auto wall0 = std::chrono::steady_clock::now();
+  HIPC(hipEventRecord(s.ev_t0, s.sc));
+  switch (r.v) {
+    case 4: launch_resident_v<4>(c, a, ntiles, r.threads, s.sc); break;
+    case 2: launch_resident_v<2>(c, a, ntiles, r.threads, s.sc); break;
+    default: launch_resident_v<1>(c, a, ntiles, r.threads, s.sc); break;
+  }
+  HIPC(hipGetLastError());
+  hipLaunchKernelGGL(lbm::lbm_fold_steps, dim3(cdiv(nsteps, lbm::kBlock / 64)), dim3(lbm::kBlock), 0, s.sc,
+                     c->rpartials, ntiles, nsteps, s.sums);
+  HIPC(hipGetLastError());
+  HIPC(hipEventRecord(s.ev_t1, s.sc));
+  s.err_host[1] = 0;
+  rc = collect_sums(c, nsteps, av_vels, wall0);
+  if (rc) return rc;
+  if (s.err_host[1] != 0) {
+    c->resident_broken = true;
+    HIPC(hipMemsetAsync(c->rabort, 0, 64, s.sc));
+    HIPC(hipStreamSynchronize(s.sc));
+    if (getenv("LBM_VERBOSE")) fprintf(stderr, "lbm: the resident kernel gave up (a tile was not scheduled); using the streaming kernels\n");
+    return LBM_OK;
+  }
+  c->cur ^= 1;
+  *done = true;
   return LBM_OK;
 }
 
@@ -1222,6 +1384,14 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
   const float a1 = c->p.density * c->p.accel / 9.f;   // d2q9-bgk.c:230-231
   const float a2 = c->p.density * c->p.accel / 36.f;
   if (c->exchange == LBM_EXCHANGE_P2P) return run_p2p(c, nsteps, av_vels);
+  if (c->exchange == 0 && c->slabs.size() == 1 && c->engine == 2 && c->rplan.tx > 0 && !c->resident_broken) {
+    bool done = false;
+    int rr = run_resident(c, nsteps, av_vels, &done);
+    if (rr) return rr;
+    if (done) { c->engine_last = 2; return LBM_OK; }
+  }
+  if (c->engine == 2) return fail(LBM_EINVAL, c->rplan.tx > 0 ? "the resident kernel gave up on this device" : "this lattice has no resident tiling (engine = 2)");
+  c->engine_last = 1;
   const bool ex = c->exchange != 0;
   const bool pairs = t2_eligible(c) && nsteps >= 2;
   int rc;
@@ -1386,6 +1556,7 @@ extern "C" int lbm_final_state(lbm_ctx* c, float* out) {
 
 extern "C" int lbm_destroy(lbm_ctx* c) {
   if (!c) return LBM_OK;
+  resident_free(c);
   for (auto& s : c->slabs) slab_free(s);
   delete c;
   return LBM_OK;
@@ -1424,16 +1595,35 @@ extern "C" int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     if (!(value == 1 || (value == 2 && c->p.nx % 2 == 0 && c->p.nx >= 4) || (value == 4 && c->p.nx % 4 == 0 && c->p.nx >= 8)))
       return fail(LBM_EINVAL, "vector_width %ld not usable with nx = %d", value, c->p.nx);
     c->V = (int)value;
+    c->engine = 1;   // (choosing among the streaming kernels selects the streaming engine)
     return LBM_OK;
   }
   if (!strcmp(key, "t2_threads")) {
     if (value != 256 && value != 512 && value != 1024) return fail(LBM_EINVAL, "t2_threads must be 256, 512 or 1024");
     c->t2_threads = (int)value;
+    c->engine = 1;
     return LBM_OK;
   }
   if (!strcmp(key, "time_block")) {
     if (value != 1 && value != 2) return fail(LBM_EINVAL, "time_block must be 1 or 2");
     c->time_block = (int)value;
+    c->engine = 1;
+    return LBM_OK;
+  }
+  if (!strcmp(key, "engine")) {
+    if (value < 0 || value > 2) return fail(LBM_EINVAL, "engine must be 0 (auto), 1 (streaming kernels) or 2 (resident kernel)");
+    if (value == 2 && (c->exchange != 0 || c->slabs.size() != 1 || c->rplan.tx == 0))
+      return fail(LBM_EINVAL, "the resident kernel needs a lattice alone on its GPU that tiles onto the CUs");
+    c->engine = (int)value;
+    if (value == 2) c->resident_broken = false;
+    return LBM_OK;
+  }
+  if (!strcmp(key, "resident_tile")) {   // tx * 100000 + ty * 10 + cells per thread
+    const int tx = (int)(value / 100000), ty = (int)((value / 10) % 10000), v = (int)(value % 10);
+    if (c->exchange != 0 || c->slabs.size() != 1 || !resident_tile_ok(c, tx, ty, v))
+      return fail(LBM_EINVAL, "resident tile %d x %d with %d cells per thread does not fit this lattice / device", tx, ty, v);
+    resident_free(c);
+    resident_set_plan(c, tx, ty, v);
     return LBM_OK;
   }
   if (!strcmp(key, "kernel_variant")) {
@@ -1452,6 +1642,14 @@ extern "C" int lbm_get_info(const lbm_ctx* c, const char* key, double* value) {
   if (!strcmp(key, "t2_threads")) { *value = c->t2_threads; return LBM_OK; }
   if (!strcmp(key, "time_block_active")) { *value = t2_eligible(c) ? 2 : 1; return LBM_OK; }
   if (!strcmp(key, "fluid_cells")) { *value = (double)c->tot_fluid; return LBM_OK; }
+  if (!strcmp(key, "engine")) { *value = c->engine; return LBM_OK; }
+  if (!strcmp(key, "engine_last")) { *value = c->engine_last; return LBM_OK; }
+  if (!strcmp(key, "engine_next")) {   // what the next lbm_run will try first
+    *value = (c->exchange == 0 && c->slabs.size() == 1 && c->engine == 2 && c->rplan.tx > 0 && !c->resident_broken) ? 2 : 1;
+    return LBM_OK;
+  }
+  if (!strcmp(key, "resident_tile")) { *value = c->rplan.tx * 100000.0 + c->rplan.ty * 10.0 + c->rplan.v; return LBM_OK; }
+  if (!strcmp(key, "compute_units")) { *value = c->ncu; return LBM_OK; }
   if (!strcmp(key, "exchange")) { *value = c->exchange; return LBM_OK; }
   if (!strcmp(key, "pitch")) { *value = c->slabs[0].pitch; return LBM_OK; }
   if (!strcmp(key, "hbm_bytes")) {
