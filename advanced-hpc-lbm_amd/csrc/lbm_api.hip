@@ -33,6 +33,7 @@
 #include "../../include/lbm_mi355x.h"
 #include "lbm_kernels.hip.h"
 #include "lbm_resident.hip.h"
+#include "lbm_march.hip.h"
 
 // ----------------------------------------------------------------- errors
 static thread_local char g_err[1024] = "";
@@ -169,8 +170,10 @@ struct lbm_ctx {
   long tot_fluid = 0;          // non-blocked cells of the GLOBAL lattice
   int V = 1;                   // cells per thread
   long variant = 0;
-  int time_block = 1;          // 2: fuse pairs of steps through LDS (lbm_sweep2) where eligible
+  int time_block = 1;          // 2: fuse pairs of steps through LDS (lbm_sweep2) where eligible;
+                               // 4: four steps per pass, row-marching (lbm_march), where eligible, then 2, then 1
   int t2_threads = 256;        // threads per tile of the two-step kernel (256 / 512 / 1024)
+  int march_rows = 0;          // rows per chunk of the marching kernel (lbm_march, time_block = 4); 0 = not chosen yet
   uint32_t seq = 0;            // peer-to-peer: sequence number of the last launch group (same on all slabs)
   bool p2p_connected = false;
   bool no_comm = false;        // rank mode without RCCL: results are this rank's contribution
@@ -278,7 +281,8 @@ int slab_alloc(lbm_ctx* c, Slab& s, bool exchanging) {
   for (int i = 0; i < 2; ++i) HIPC(hipMalloc((void**)&s.lat[i], lat_bytes));
   HIPC(hipMalloc((void**)&s.blocked, (size_t)s.plane));
   // one partial per block; worst case V = 1, one launch covering all rows (+2 for split launches)
-  s.partial_cap = std::max(cdiv((long)s.nyl * nx, lbm::kBlock), 2 * cdiv(nx, kT2X) * cdiv(s.nyl, kT2Y)) + 8;
+  s.partial_cap = std::max({cdiv((long)s.nyl * nx, lbm::kBlock), 2 * cdiv(nx, kT2X) * cdiv(s.nyl, kT2Y),
+                            4 * cdiv(nx, 224) * s.nyl}) + 8;   // (last: the marching kernel with one-row chunks)
   for (int i = 0; i < 2; ++i) HIPC(hipMalloc((void**)&s.partials[i], sizeof(float) * s.partial_cap));
   s.scratch_cap = s.partial_cap;
   HIPC(hipMalloc((void**)&s.scratch_d, sizeof(double) * (s.scratch_cap + 8)));
@@ -395,17 +399,44 @@ void pick_defaults(lbm_ctx* c) {
   const char* e;
   if ((e = getenv("LBM_VECTOR_WIDTH"))) c->V = pick_vector_width(nx);
   if ((e = getenv("LBM_KERNEL_VARIANT"))) c->variant = atol(e) & 7;
-  if ((e = getenv("LBM_TIME_BLOCK"))) c->time_block = atoi(e) == 2 ? 2 : 1;
+  if ((e = getenv("LBM_TIME_BLOCK"))) c->time_block = atoi(e) == 4 ? 4 : atoi(e) == 2 ? 2 : 1;
   if ((e = getenv("LBM_T2_THREADS"))) { const int t = atoi(e); if (t == 256 || t == 512 || t == 1024) c->t2_threads = t; }
 }
 
 // The two-step kernel covers whole 64 x 16 tiles.  With neighbours every slab must tile too,
 // and every rank must come to the same answer (the halo message size depends on it).
 bool t2_eligible(const lbm_ctx* c) {
-  if (c->time_block != 2) return false;
+  if (c->time_block < 2) return false;
   // a slab alone: any lattice of at least one tile (partial tiles at the east / north end)
   if (c->exchange == 0) return c->slabs.size() == 1 && c->p.nx >= kT2X && c->p.ny >= kT2Y;
   return c->p.nx % kT2X == 0 && c->p.ny % (c->nranks * kT2Y) == 0;
+}
+
+// Steps per pass of the marching kernel (lbm_march.hip.h).
+constexpr int kMarchK = 4;
+
+// The marching kernel runs on a lattice alone on its GPU (periodic wrap inside the kernel); its row
+// fetches are 16-byte LDS-DMA pieces, so columns must come in fours, and a strip is 256 columns wide.
+bool march_eligible(const lbm_ctx* c) {
+  return c->time_block == 4 && c->exchange == 0 && c->slabs.size() == 1 && c->p.nx % 4 == 0 &&
+         c->p.nx >= lbm::MarchCfg<kMarchK>::W && c->p.ny >= 2 * kMarchK &&
+         (double)c->p.ny * c->slabs[0].pitch * 4.0 < 4.0e9;   // 32-bit byte offsets inside a plane
+}
+
+// Rows per chunk: every block pays 3 (K-1) fill iterations, and the grid should come out a little
+// under a whole number of rounds of one block per CU.
+int march_pick_rows(const lbm_ctx* c) {
+  const int ns = cdiv(c->p.nx, lbm::MarchCfg<kMarchK>::WOUT), ncu = std::max(c->ncu, 1), ny = c->p.ny;
+  int best_h = std::min(ny, 256);
+  double best = -1.0;
+  for (int h = std::min(ny, 32); h <= std::min(ny, 1024); ++h) {
+    const long blocks = (long)ns * cdiv(ny, h);
+    const long rounds = (blocks + ncu - 1) / ncu;
+    // useful rows over rows of time: `rounds` rounds of full-height blocks on every CU
+    const double eff = (double)ny * ns / ((double)rounds * ncu * (h + 3 * (kMarchK - 1)));
+    if (eff > best + 1e-9) { best = eff; best_h = h; }
+  }
+  return best_h;
 }
 
 // Tiles of a lone slab (partial ones included).
@@ -1049,6 +1080,37 @@ int launch_pair(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev, floa
   return LBM_OK;
 }
 
+// One marching launch: steps tt .. tt+K-1 of the lone slab, launch index li.
+int launch_march(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev) {
+  using Cfg = lbm::MarchCfg<kMarchK>;
+  Slab& s = c->slabs[0];
+  HIPC(hipSetDevice(s.dev));
+  if (c->march_rows <= 0) c->march_rows = march_pick_rows(c);
+  const int q = li & 1, qp = q ^ 1;
+  lbm::MarchArgs a;
+  a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
+  a.plane = s.plane; a.pitch = s.pitch; a.nx = c->p.nx; a.ny = c->p.ny;
+  a.blocked = s.blocked; a.omega = c->p.omega;
+  a.accel_row = c->p.ny - 2; a.accel_out = accel_out ? 1 : 0;
+  a.a1 = c->p.density * c->p.accel / 9.f; a.a2 = c->p.density * c->p.accel / 36.f;
+  a.H = c->march_rows;
+  a.nstrips = cdiv(c->p.nx, Cfg::WOUT); a.nchunks = cdiv(c->p.ny, a.H);
+  const int nb = a.nstrips * a.nchunks;
+  if ((long)kMarchK * nb > s.partial_cap) return fail(LBM_EINVAL, "marching kernel: %d blocks exceed the partial-sum buffer", nb);
+  a.partials = s.partials[q];
+  a.prev = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
+  if (fold_prev) { a.prev = s.partials[qp]; a.prev_count = nb; a.prev_sum = s.sums + (tt - kMarchK); }
+  switch ((int)(c->variant & (lbm::kFastMath | lbm::kNtStore))) {
+    case 0: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 0>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
+    case 1: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 1>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
+    case 2: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 2>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
+    default: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 3>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
+  }
+  HIPC(hipGetLastError());
+  c->cur ^= 1;
+  return LBM_OK;
+}
+
 }  // namespace
 
 namespace {
@@ -1431,8 +1493,18 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
   // Launch index li numbers the launch groups (a pair of steps or a single step); its parity
   // selects the halo / partial-sum buffers.
   int li = 0, tt = 0;
-  if (pairs) {
-    const int npairs = nsteps / 2;
+  if (march_eligible(c) && nsteps >= kMarchK) {   // groups of K steps, row-marching (lone slab)
+    const int ngroups = nsteps / kMarchK;
+    for (int g = 0; g < ngroups; ++g, ++li, tt += kMarchK)
+      if ((rc = launch_march(c, li, tt, tt + kMarchK < nsteps, g > 0))) return rc;
+    Slab& s = c->slabs[0];
+    const int nb = cdiv(nx, lbm::MarchCfg<kMarchK>::WOUT) * cdiv(c->p.ny, c->march_rows);
+    hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(kMarchK), dim3(lbm::kBlock), 0, s.sc, s.partials[(li - 1) & 1], nb,
+                       s.sums + (tt - kMarchK), nb);
+    HIPC(hipGetLastError());
+  }
+  if (pairs && nsteps - tt >= 2) {
+    const int npairs = (nsteps - tt) / 2;
     for (int j = 0; j < npairs; ++j, ++li, tt += 2)
       if ((rc = launch_pair(c, li, tt, tt + 2 < nsteps, j > 0, a1, a2))) return rc;
     const int ql = (li - 1) & 1;
@@ -1604,8 +1676,13 @@ extern "C" int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     c->engine = 1;
     return LBM_OK;
   }
+  if (!strcmp(key, "march_rows")) {
+    if (value < 1 || value > c->p.ny) return fail(LBM_EINVAL, "march_rows must be in [1, ny]");
+    c->march_rows = (int)value;
+    return LBM_OK;
+  }
   if (!strcmp(key, "time_block")) {
-    if (value != 1 && value != 2) return fail(LBM_EINVAL, "time_block must be 1 or 2");
+    if (value != 1 && value != 2 && value != 4) return fail(LBM_EINVAL, "time_block must be 1, 2 or 4");
     c->time_block = (int)value;
     c->engine = 1;
     return LBM_OK;
@@ -1640,7 +1717,8 @@ extern "C" int lbm_get_info(const lbm_ctx* c, const char* key, double* value) {
   if (!strcmp(key, "kernel_variant")) { *value = (double)c->variant; return LBM_OK; }
   if (!strcmp(key, "time_block")) { *value = c->time_block; return LBM_OK; }
   if (!strcmp(key, "t2_threads")) { *value = c->t2_threads; return LBM_OK; }
-  if (!strcmp(key, "time_block_active")) { *value = t2_eligible(c) ? 2 : 1; return LBM_OK; }
+  if (!strcmp(key, "time_block_active")) { *value = march_eligible(c) ? 4 : t2_eligible(c) ? 2 : 1; return LBM_OK; }
+  if (!strcmp(key, "march_rows")) { *value = c->march_rows > 0 ? c->march_rows : march_pick_rows(c); return LBM_OK; }
   if (!strcmp(key, "fluid_cells")) { *value = (double)c->tot_fluid; return LBM_OK; }
   if (!strcmp(key, "engine")) { *value = c->engine; return LBM_OK; }
   if (!strcmp(key, "engine_last")) { *value = c->engine_last; return LBM_OK; }
