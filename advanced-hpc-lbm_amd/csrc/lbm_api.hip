@@ -425,15 +425,21 @@ bool march_eligible(const lbm_ctx* c) {
 
 // Rows per chunk: every block pays 3 (K-1) fill iterations, and the grid should come out a little
 // under a whole number of rounds of one block per CU.
-int march_pick_rows(const lbm_ctx* c) {
+// Useful rows over rows of time for chunks of h rows: `rounds` rounds of full-height blocks on every CU,
+// each paying its fill iterations.
+double march_efficiency(const lbm_ctx* c, int h) {
   const int ns = cdiv(c->p.nx, lbm::MarchCfg<kMarchK>::WOUT), ncu = std::max(c->ncu, 1), ny = c->p.ny;
+  const long blocks = (long)ns * cdiv(ny, h);
+  const long rounds = (blocks + ncu - 1) / ncu;
+  return (double)ny * ns / ((double)rounds * ncu * (h + 3 * (kMarchK - 1)));
+}
+
+int march_pick_rows(const lbm_ctx* c) {
+  const int ny = c->p.ny;
   int best_h = std::min(ny, 256);
   double best = -1.0;
   for (int h = std::min(ny, 32); h <= std::min(ny, 1024); ++h) {
-    const long blocks = (long)ns * cdiv(ny, h);
-    const long rounds = (blocks + ncu - 1) / ncu;
-    // useful rows over rows of time: `rounds` rounds of full-height blocks on every CU
-    const double eff = (double)ny * ns / ((double)rounds * ncu * (h + 3 * (kMarchK - 1)));
+    const double eff = march_efficiency(c, h);
     if (eff > best + 1e-9) { best = eff; best_h = h; }
   }
   return best_h;
@@ -635,6 +641,14 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
     const char* e = getenv("LBM_ENGINE");
     if (e) c->engine = (atoi(e) >= 0 && atoi(e) <= 2) ? atoi(e) : 0;
     if (!exchanging && c->slabs.size() == 1) plan_resident(c);
+    // Four steps per pass (lbm_march) where its strips and chunks fill the chip: measured 1.5-1.6x
+    // lbm_sweep2 from 2048^2 up (194 / 226 / 238 GLUPS at 2048^2 / 4096^2 / 8192^2 against 129 / 146 /
+    // 150), 0.8x at 1024^2, where 5 strips x 32-row chunks leave the CUs 49 % busy by the estimate
+    // below (2048^2: 88 %).
+    if (!getenv("LBM_TIME_BLOCK") && c->time_block == 2) {
+      c->time_block = 4;
+      if (!march_eligible(c) || march_efficiency(c, march_pick_rows(c)) < 0.65) c->time_block = 2;
+    }
   }
   return LBM_OK;
 }

@@ -12,10 +12,11 @@ the synthetic 8192x8192 lattice of BASELINE.json is measured in the same run and
 under "also".  Inputs are resident in HBM before the timed region; exactly K steps are
 timed between barrier + torch.cuda.synchronize() pairs; the maximum over ranks is used.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the sweep kernel against HBM:
-72 algorithmic bytes per lattice update (9 float reads + 9 float writes, mask excluded)
-x the cells one launch covers / the mean launch time measured with HIP events on the
-library's own compute stream.  `cpu_baseline` times the serial reference on this host
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against HBM: the bytes
+its blocking scheme must move per lattice update (72 for one step per pass, 38.9 for two, 19.4
+for four: kernel_of) x the updates one launch covers / the mean launch time measured with HIP
+events on the library's own compute stream; the rate priced at the one-step kernel's 72 B per
+update is reported beside it as equiv_72B_*.  `cpu_baseline` times the serial reference on this host
 (oracle/_ref/d2q9-bgk, built from the reference's own source; else our port) on a bounded
 sample of the same deck.
 """
@@ -154,15 +155,9 @@ def choose_exchange(p, ob, world, rank, local_rank):
     ok_r, note_r, secs_r = probe(L.EXCHANGE_RCCL)
     extra = ""
     if not ok_r:
-        # last resort: one step per launch, one-row halos (the simplest protocol)
-        os.environ["LBM_TIME_BLOCK"] = "1"
-        with L.Lattice(p, ob, nslabs=1, devices=[local_rank]) as whole:
-            av_true = np.concatenate([whole.run(6), whole.run(3)])
-            st_true = whole.read_state()[rb:re_].copy()
-        ok_r2, note_r2, secs_r = probe(L.EXCHANGE_RCCL)
-        if not ok_r2:
-            raise SystemExit(f"halo exchange failed its check against the undivided lattice: {note_r}; one step per launch: {note_r2}")
-        extra = f" [two-step halos failed the check ({note_r}): one step per launch]"
+        # no quiet fallback to one step per launch with one-row RCCL halos: that path costs ~200 us per
+        # step on 1024^2 (profiles/r01_slab_overheads_one_gpu.log), which is not a benchmark of anything
+        raise SystemExit(f"RCCL halo exchange failed its check against the undivided lattice: {note_r}")
     ok_p, note_p, secs_p = probe(L.EXCHANGE_P2P)
     if not ok_p:
         return L.EXCHANGE_RCCL, "RCCL send/recv (peer-to-peer halos not usable here: %s)%s" % (note_p or "failure on another rank", extra)
@@ -175,8 +170,25 @@ def choose_exchange(p, ob, world, rank, local_rank):
                             % (secs_p * 1e3, secs_r * 1e3, probe_steps, extra))
 
 
+def kernel_of(lat, tb):
+    """(name, minimum HBM bytes per lattice update) of the kernel the timed run used.  The minimum is what
+    the kernel's own blocking scheme must move (obstacle bytes excluded):
+      lbm_sweep    one step per pass                      36 read + 36 written          = 72
+      lbm_sweep2   two steps per pass, 64x16 tiles + ring  (36 x 66x18/(64x16) + 36) / 2 = 38.9
+      lbm_march    four steps per pass, 224 of 256 columns (36 x 258/224 + 36) / 4       = 19.4
+      lbm_resident whole run in LDS: one load and one store of the lattice per RUN (reported per step)"""
+    if int(lat.info("engine_last")) == 2:
+        return "lbm_resident", None
+    if tb == 4:
+        return "lbm_march<4>", (36.0 * 258 / 224 + 36.0) / 4
+    if tb == 2:
+        return "lbm_sweep2<64,16>", (36.0 * (66 * 18) / (64 * 16) + 36.0) / 2
+    return f"lbm_sweep<{int(lat.info('vector_width'))}>", 72.0
+
+
 def measure(name, world, rank, local_rank, steps, warmup):
-    """Creates the resident lattice, warms up, times exactly `steps` steps."""
+    """Creates the resident lattice, warms up, times exactly `steps` steps; at N > 1 every rank then
+    repeats the same steps on the UNDIVIDED lattice alone on its GPU and compares its slab bit for bit."""
     p, ob, data = make_workload(name)
     exchange, halo_note = choose_exchange(p, ob, world, rank, local_rank)
     lat = make_lattice(p, ob, world, rank, local_rank, exchange)
@@ -200,20 +212,38 @@ def measure(name, world, rank, local_rank, steps, warmup):
         t = torch.tensor([dt, gpu_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, gpu_ms = t[0].item(), t[1].item()
-    vw = int(lat.info("vector_width"))
-    tb = int(lat.info("time_block_active"))              # 2: two steps per launch (lbm_sweep2)
+    tb = int(lat.info("time_block_active"))              # steps per launch: 4 lbm_march, 2 lbm_sweep2, 1 lbm_sweep
+    kernel, min_bytes = kernel_of(lat, tb)
     # stale or missing halos would break the mass balance at the slab boundaries long before anything
-    # goes non-finite; float32 rounding alone drifts ~1e-8 per step (tests/test_gpu_parity.py)
+    # goes non-finite; float32 rounding alone drifts ~2e-8 per step (tests/test_gpu_parity.py)
     mass_drift = abs(lat.total_density() - mass0) / mass0
+    bitexact = None
+    if MULTI:
+        # every decomposition and transport is bit-identical to the undivided lattice by construction
+        # and by test: check it on THIS machine for THIS run, all warmup + steps steps of it
+        ok = True
+        try:
+            mine = lat.read_state()
+            with L.Lattice(p, ob, nslabs=1, devices=[local_rank]) as whole:
+                av_w = np.concatenate([whole.run(warmup), whole.run(steps)]) if warmup > 0 else whole.run(steps)
+                ref = whole.read_state()[r0:r1]
+            ok = bool(np.array_equal(mine.view(np.uint32), ref.view(np.uint32)) and
+                      np.allclose(av, av_w[warmup:], rtol=2e-6, atol=0))
+        except Exception as e:          # (every rank still reaches the collective below)
+            ok = False
+            print(f"rank {rank}: post-run check failed: {type(e).__name__}: {e}", file=sys.stderr)
+        bitexact = all_ranks_agree(ok, world)
     fence()
     lat.close()
     cells = p.nx * p.ny
     local_cells = p.nx * (r1 - r0)
-    kernel = "lbm_sweep2<64,16>" if tb == 2 else f"lbm_sweep<{vw}>"
-    launches = steps // tb + steps % tb
+    launches = steps // tb + (steps % tb) // 2 + (steps % tb) % 2 if tb == 4 else steps // tb + steps % tb
     launch_s = gpu_ms * 1e-3 / launches                  # mean duration of one launch on this GPU
-    bytes_per_launch = BYTES_PER_LUP * local_cells * steps / launches   # algorithmic bytes one launch covers
-    achieved = bytes_per_launch / launch_s / 1e9
+    lups_per_launch = local_cells * steps / launches
+    if min_bytes is None:                                # resident: the lattice crosses HBM twice per run
+        min_bytes = 72.0 / steps
+    achieved = min_bytes * lups_per_launch / launch_s / 1e9
+    equiv72 = BYTES_PER_LUP * lups_per_launch / launch_s / 1e9
     traffic = lookup_traffic(name, world, kernel)
     return {
         "mlups": cells * steps / dt / 1e6,
@@ -221,16 +251,20 @@ def measure(name, world, rank, local_rank, steps, warmup):
         "gpu_ms_per_step": gpu_ms / steps,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": kernel, "lattice_updates_per_launch": local_cells * steps / launches,
-                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "kernel": kernel, "steps_per_launch": tb,
+                     # `achieved` prices a lattice update at the bytes THIS kernel's blocking must move
+                     # (kernel_of), so frac <= 1 by construction; the same rate priced at the one-step
+                     # kernel's 72 B per update is reported separately and may exceed 1
+                     "min_bytes_per_lattice_update": round(min_bytes, 3),
+                     "lattice_updates_per_launch": lups_per_launch,
                      "launch_us": round(launch_s * 1e6, 3),
-                     # what actually crossed the HBM interface (PMC bytes / measured launch time): the
-                     # two-step kernel moves ~38 B per update instead of the 72 B `achieved` prices, so
-                     # frac > 1 means temporal blocking, not more than the pins can carry
+                     "equiv_72B_gbs": round(equiv72, 1), "equiv_72B_frac": round(equiv72 / HBM_PEAK_GBS, 4),
+                     # what actually crossed the HBM interface: PMC bytes per launch (profiles/hbm_traffic.json,
+                     # collected on the box and commit named there) / this run's launch time
                      "traffic_gbs": None if traffic is None else round(traffic / launch_s / 1e9, 1),
                      "traffic_frac_of_peak": None if traffic is None else round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4)},
         "data": data, "params": p, "blocked": int(ob.sum()), "av_last": float(av[-1]), "finite": bool(np.isfinite(av).all()),
-        "halo": halo_note, "mass_drift": mass_drift,
+        "halo": halo_note, "mass_drift": mass_drift, "bitexact": bitexact,
     }
 
 
@@ -357,17 +391,26 @@ def main():
                        "halo": head["halo"]},
             "roofline": head["roofline"],
             "cpu_baseline": cpu,
-            "hbm_frac_of_peak_whole_job": round(head["mlups"] * BYTES_PER_LUP / 1e3 / (HBM_PEAK_GBS * world), 4),
+            "equiv_72B_frac_whole_job": round(head["mlups"] * BYTES_PER_LUP / 1e3 / (HBM_PEAK_GBS * world), 4),
+            "gpu_ms_per_step": round(head["gpu_ms_per_step"], 6),          # HIP events around the step loop
+            "value_gpu_events": round(p.nx * p.ny / head["gpu_ms_per_step"] / 1e3, 1),   # MLUPS by that clock
+            "speedup_vs_cpu_baseline": None if not cpu else round(head["mlups"] / cpu["value"], 1),
             "results_finite": head["finite"],
             "mass_drift": float("%.3g" % head["mass_drift"]),
-            "results_valid": bool(head["finite"] and head["mass_drift"] < 1e-6 * (args.steps + args.warmup) + 1e-5),
+            # N > 1: this run's slabs, all warmup + steps steps, against the undivided lattice on every rank
+            "results_bitexact": head["bitexact"],
+            "halo_verified": head["bitexact"],
+            "results_valid": bool(head["finite"] and head["mass_drift"] < 1e-7 * (args.steps + args.warmup) + 1e-6
+                                  and head["bitexact"] is not False),
         }
         if also is not None:
             line["also"] = {args.also: {
                 "value": round(also["mlups"], 1), "unit": "MLUPS", "steps": args.also_steps,
                 "ms_per_step": round(also["ms_per_step"], 6), "roofline": also["roofline"], "data": also["data"],
-                "halo": also["halo"],
-                "hbm_frac_of_peak_whole_job": round(also["mlups"] * BYTES_PER_LUP / 1e3 / (HBM_PEAK_GBS * world), 4)}}
+                "halo": also["halo"], "results_bitexact": also["bitexact"],
+                "equiv_72B_frac_whole_job": round(also["mlups"] * BYTES_PER_LUP / 1e3 / (HBM_PEAK_GBS * world), 4)}}
+            if also["bitexact"] is False:
+                line["results_valid"] = False
         result_out.write(json.dumps(line) + "\n")
         result_out.flush()
     if MULTI:

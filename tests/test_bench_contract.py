@@ -31,7 +31,13 @@ def test_bench_line_single_gpu(gpu):
     ro = d["roofline"]
     assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0
     assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
+    assert 0.0 < ro["frac"] <= 1.0                         # priced at the kernel's own minimum bytes: a real fraction
+    assert ro["kernel"].startswith("lbm_sweep2") and abs(ro["min_bytes_per_lattice_update"] - 38.88) < 0.01
+    assert ro["equiv_72B_frac"] > ro["frac"] and abs(ro["equiv_72B_gbs"] / ro["achieved"] - 72.0 / ro["min_bytes_per_lattice_update"]) < 1e-2
     assert ro["traffic"] is None or ro["traffic"] > 0
+    big = d["also"]["8192x8192"]["roofline"]
+    assert big["kernel"] == "lbm_march<4>" and big["steps_per_launch"] == 4 and 0.0 < big["frac"] <= 1.0
+    assert d["gpu_ms_per_step"] <= d["ms_per_step"] and d["results_bitexact"] is None
     cb = d["cpu_baseline"]
     assert cb["unit"] == "MLUPS" and cb["cores"] == 1 and cb["kind"] in ("reference", "port") and cb["value"] > 1
     assert d["results_finite"] is True
@@ -46,3 +52,4 @@ def test_bench_multi_rank_path_rehearsal(gpu):
     assert d["cpu_baseline"] is None
     assert "peer-to-peer" in d["config"]["halo"] or "RCCL" in d["config"]["halo"]
     assert "REHEARSAL" in d["config"]["decomposition"]
+    assert d["results_bitexact"] is True and d["halo_verified"] is True and d["results_valid"] is True

@@ -93,14 +93,17 @@ def test_fifty_steps_against_float_oracle(gpu, O, oracle, deck):
     # 7 = that + nontemporal loads and stores (the flavours the library picks by lattice size)
     # (time_block 1 = the one-step kernel lbm_sweep<V>, which is what V selects; 2 = lbm_sweep2, where
     # the flavour bits still apply)
-    combos = [(1, V, variant) for V in (4, 2, 1) for variant in (0, 1, 6, 7)] + [(2, 4, 0), (2, 4, 1), (2, 4, 3)]
+    # (time_block 1 = the one-step kernel lbm_sweep<V>, which is what V selects; 2 = lbm_sweep2 and 4 = lbm_march
+    # (lattices of at least 256 columns; else it falls back to 2), where the flavour bits still apply)
+    combos = [(1, V, variant) for V in (4, 2, 1) for variant in (0, 1, 6, 7)] + [(2, 4, 0), (2, 4, 1), (2, 4, 3),
+                                                                                  (4, 4, 0), (4, 4, 1), (4, 4, 3)]
     for tb, V, variant in combos:
         with L.Lattice(p, ob) as lat:
             lat.set_option("time_block", tb)
             lat.set_option("vector_width", V)
             lat.set_option("kernel_variant", variant)
             assert lat.info("vector_width") == V and lat.info("kernel_variant") == variant
-            assert lat.info("time_block_active") == tb
+            assert lat.info("time_block_active") == (tb if tb < 4 or p.nx >= 256 else 2)
             av = lat.run(50)
             st = lat.read_state()
             fs = lat.final_state()
@@ -801,3 +804,100 @@ def test_cli_row_partitioned_default_exchange_on_one_gpu(gpu, tmp_path):
     r2 = subprocess.run([exe, pf, of], cwd=two, capture_output=True, text=True, env=env)
     assert r1.returncode == 0 and r2.returncode == 0, r2.stderr
     assert (one / "final_state.dat").read_bytes() == (two / "final_state.dat").read_bytes()
+
+
+def _random_case(L, nx, ny, seed, blocked=0.1):
+    rng = np.random.default_rng(seed)
+    p = L.Param(nx, ny, 100, 10, 0.1, 0.01, 1.85)
+    ob = (rng.random((ny, nx)) < blocked).astype(np.int32)
+    w = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4, dtype=np.float32)
+    cells = (0.1 * w * (1.0 + 0.2 * (rng.random((ny, nx, 9), dtype=np.float32) - 0.5))).astype(np.float32)
+    return p, ob, cells
+
+
+@pytest.mark.parametrize("nx,ny,rows,steps", [
+    (256, 64, 0, [4]), (256, 64, 16, [4]), (256, 64, 7, [8, 5]),      # one strip; chunks that wrap in y; ragged last chunk
+    (260, 40, 0, [4]), (448, 100, 33, [12]), (480, 70, 0, [13]),      # partial last strip; 13 = 3 x 4 + a single step
+    (1000, 24, 8, [9]), (2048, 512, 0, [8]), (1024, 1024, 0, [16, 3]),
+])
+def test_marching_kernel_equals_single_step_kernel(gpu, nx, ny, rows, steps):
+    """lbm_march (four steps per pass, row-marching through LDS rings fed by LDS-DMA) against the plain
+    one-step kernel on random lattices: bit-identical state after groups of four steps plus remainders
+    (pairs through lbm_sweep2, a trailing single step), av_vels within summation order."""
+    L = gpu
+    p, ob, cells = _random_case(L, nx, ny, 7)
+    with L.Lattice(p, ob, cells) as a:
+        a.set_option("time_block", 1)
+        av_a = np.concatenate([a.run(n) for n in steps])
+        st_a = a.read_state()
+    with L.Lattice(p, ob, cells) as b:
+        b.set_option("time_block", 4)
+        if rows:
+            b.set_option("march_rows", rows)
+        assert b.info("time_block_active") == 4
+        av_b = np.concatenate([b.run(n) for n in steps])
+        st_b = b.read_state()
+    assert np.array_equal(st_a.view(np.uint32), st_b.view(np.uint32))
+    assert np.allclose(av_a, av_b, rtol=2e-6, atol=0)
+
+
+def test_marching_kernel_is_the_default_on_big_lattices_only(gpu):
+    """time_block defaults to 4 where the strips and chunks of lbm_march fill the chip (2048^2 and up), to 2
+    on the shipped decks; narrow lattices cannot march at all."""
+    L = gpu
+    for n, want in ((2048, 4), (1024, 2), (256, 2)):
+        p = L.Param(n, n, 10, 10, 0.1, 0.01, 1.85)
+        with L.Lattice(p, np.zeros((n, n), dtype=np.int32)) as lat:
+            assert lat.info("time_block_active") == want, n
+    p = L.Param(128, 4096, 10, 10, 0.1, 0.01, 1.85)
+    with L.Lattice(p, np.zeros((4096, 128), dtype=np.int32)) as lat:
+        lat.set_option("time_block", 4)
+        assert lat.info("time_block_active") == 2
+
+
+@pytest.mark.parametrize("tile,nx,ny,steps", [
+    ((16, 16, 1), 64, 64, [1]), ((16, 16, 1), 64, 64, [7, 4]), ((16, 16, 4), 64, 64, [9]), ((32, 32, 2), 64, 64, [9]),
+    ((64, 64, 4), 64, 64, [9]),                      # one tile: it is its own neighbour on all eight sides
+    (None, 128, 256, [12]), ((32, 16, 4), 96, 80, [10]), ((8, 5, 1), 96, 80, [10]), ((8, 12, 2), 40, 36, [10]),
+    (None, 1024, 1024, [21]),
+])
+def test_resident_kernel_equals_single_step_kernel(gpu, tile, nx, ny, steps):
+    """lbm_resident (engine 2: the whole run in one launch, tiles in LDS, tagged 8-byte granules between
+    neighbouring tiles through L2) against the one-step streaming kernel: bit-identical lattice."""
+    L = gpu
+    p, ob, cells = _random_case(L, nx, ny, 11)
+    with L.Lattice(p, ob, cells) as a:
+        a.set_option("time_block", 1)
+        av_a = np.concatenate([a.run(n) for n in steps])
+        st_a = a.read_state()
+    with L.Lattice(p, ob, cells) as b:
+        b.set_option("engine", 2)
+        if tile is not None:
+            b.set_option("resident_tile", tile[0] * 100000 + tile[1] * 10 + tile[2])
+        av_b = np.concatenate([b.run(n) for n in steps])
+        assert b.info("engine_last") == 2
+        st_b = b.read_state()
+    assert np.array_equal(st_a.view(np.uint32), st_b.view(np.uint32))
+    assert np.allclose(av_a, av_b, rtol=2e-6, atol=0)
+
+
+def test_cli_on_generated_deck(gpu, tmp_path):
+    """tools/make_deck.py writes params + obstacle files the CLI reads (d2q9-bgk.c:2736-2762, 2844-2857):
+    a 2048 x 2048 deck end to end (final_state.dat skipped), av_vels.dat against Lattice.run on the same map."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_deck
+    L = gpu
+    pf, of, nb = make_deck.write_deck(2048, 2048, 40, outdir=str(tmp_path))
+    exe = os.path.join(ROOT, "d2q9-bgk")
+    r = subprocess.run([exe, pf, of], cwd=tmp_path, capture_output=True, text=True,
+                       env=dict(os.environ, LBM_SKIP_FINAL_STATE="1"))
+    assert r.returncode == 0, r.stderr
+    assert not (tmp_path / "final_state.dat").exists()
+    av_cli = np.loadtxt(tmp_path / "av_vels.dat", usecols=[1])
+    p = L.read_params(pf)
+    ob = L.read_obstacles(of, p)
+    assert int(ob.sum()) == nb and np.array_equal(ob, make_deck.obstacle_map(2048, 2048))
+    with L.Lattice(p, ob) as lat:
+        av = lat.run(40)
+    assert np.allclose(av_cli, av, rtol=1e-6, atol=0)       # (%.12E text of a float32)

@@ -178,3 +178,20 @@ def test_cli_usage_and_die_convention(tmp_path):
     assert r.returncode == 1 and r.stderr.splitlines()[1] == "expected 3 values per line in obstacle file"
     r = subprocess.run([EXE, str(pf), str(tmp_path / "none.dat")], capture_output=True, text=True)
     assert r.returncode == 1 and r.stderr.splitlines()[1].startswith("could not open input obstacles file: ")
+
+
+def test_deck_generator_reproduces_the_shipped_1024_deck(tmp_path):
+    """tools/make_deck.py at 1024 x 1024 = the shipped deck: identical params file, identical set of blocked
+    cells (the shipped obstacle file lists a few cells twice); bench.py's in-memory map is the same function."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_deck
+    pf, of, nb = make_deck.write_deck(1024, 1024, 20000, outdir=str(tmp_path))
+    assert open(pf).read() == open(os.path.join(ROOT, "input_1024x1024.params")).read()
+    mine = np.loadtxt(of, dtype=int)
+    ref = np.loadtxt(os.path.join(ROOT, "obstacles_1024x1024.dat"), dtype=int)
+    assert set(map(tuple, mine)) == set(map(tuple, ref)) and nb == 5114 and np.all(mine[:, 2] == 1)
+    assert make_deck.wall_x(8192) == 2730
+    big = make_deck.obstacle_map(8192, 64)
+    assert big[:, 2730].all() and big[0].all() and big[-1].all() and big[:, 0].all() and big[:, -1].all()
+    assert int(big[1:-1, 1:-1].sum()) == 62       # the wall only
