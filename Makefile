@@ -7,7 +7,10 @@ EXE=d2q9-bgk
 CC=gcc
 HIPCC=hipcc
 CFLAGS= -std=c99 -Wall -O2 -fopenmp
-HIPFLAGS= -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -Wno-align-mismatch
+# -fno-slp-vectorize: the SLP vectoriser packs pairs of float operations into v_pk_* instructions, which on
+# gfx950 are no faster than the two scalar ones and cost v_mov's to assemble their operands
+# (8192^2, same box: lbm_march 237 -> 269 GLUPS, lbm_wave<8> 227 -> 262, lbm_sweep2 at 1024^2 132 -> 135)
+HIPFLAGS= -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -Wno-align-mismatch -fno-slp-vectorize
 PKG=advanced-hpc-lbm_amd
 LIB=$(PKG)/liblbm_mi355x.so
 
@@ -20,13 +23,16 @@ all: $(EXE)
 
 lib: $(LIB)
 
-$(LIB): $(PKG)/csrc/lbm_api.hip $(PKG)/csrc/lbm_kernels.hip.h $(PKG)/csrc/lbm_resident.hip.h $(PKG)/csrc/lbm_march.hip.h include/lbm_mi355x.h
+$(LIB): $(PKG)/csrc/lbm_api.hip $(PKG)/csrc/lbm_kernels.hip.h $(PKG)/csrc/lbm_resident.hip.h $(PKG)/csrc/lbm_march.hip.h $(PKG)/csrc/lbm_wave.hip.h include/lbm_mi355x.h
 	$(HIPCC) $(HIPFLAGS) -shared $< -o $@ -ldl -Wl,-rpath,/opt/rocm/lib
 
 $(EXE): $(PKG)/host/d2q9-bgk.c $(LIB) include/lbm_mi355x.h
 	$(CC) $(CFLAGS) -Iinclude $< -o $@ -L$(PKG) -llbm_mi355x -Wl,-rpath,'$$ORIGIN/$(PKG)' -Wl,-rpath,/opt/rocm/lib
 
-tools: tools/kbench
+tools: tools/kbench tools/layout_bench
+
+tools/layout_bench: tools/layout_bench.hip
+	$(HIPCC) $(HIPFLAGS) $< -o $@
 
 tools/kbench: tools/kbench.hip $(PKG)/csrc/lbm_kernels.hip.h
 	$(HIPCC) $(HIPFLAGS) $< -o $@
@@ -40,4 +46,4 @@ check:
 .PHONY: all lib tools oracle check clean
 
 clean:
-	rm -f $(EXE) $(LIB) tools/kbench
+	rm -f $(EXE) $(LIB) tools/kbench tools/layout_bench

@@ -34,6 +34,7 @@
 #include "lbm_kernels.hip.h"
 #include "lbm_resident.hip.h"
 #include "lbm_march.hip.h"
+#include "lbm_wave.hip.h"
 
 // ----------------------------------------------------------------- errors
 static thread_local char g_err[1024] = "";
@@ -174,6 +175,10 @@ struct lbm_ctx {
                                // 4: four steps per pass, row-marching (lbm_march), where eligible, then 2, then 1
   int t2_threads = 256;        // threads per tile of the two-step kernel (256 / 512 / 1024)
   int march_rows = 0;          // rows per chunk of the marching kernel (lbm_march, time_block = 4); 0 = not chosen yet
+  int march_kernel = 1;        // which marching kernel runs time_block >= 4: 0 = lbm_march (one block per strip, LDS rings,
+                               // K = 4 only), 1 = lbm_wave (one wave per strip, register pipeline, K = 4 / 6 / 8)
+  int wave_rows = 0;           // rows per chunk of lbm_wave; 0 = not chosen yet
+  int wave_capacity = 0;       // waves of lbm_wave<time_block> the device holds at once (occupancy query)
   uint32_t seq = 0;            // peer-to-peer: sequence number of the last launch group (same on all slabs)
   bool p2p_connected = false;
   bool no_comm = false;        // rank mode without RCCL: results are this rank's contribution
@@ -282,7 +287,8 @@ int slab_alloc(lbm_ctx* c, Slab& s, bool exchanging) {
   HIPC(hipMalloc((void**)&s.blocked, (size_t)s.plane));
   // one partial per block; worst case V = 1, one launch covering all rows (+2 for split launches)
   s.partial_cap = std::max({cdiv((long)s.nyl * nx, lbm::kBlock), 2 * cdiv(nx, kT2X) * cdiv(s.nyl, kT2Y),
-                            4 * cdiv(nx, 224) * s.nyl}) + 8;   // (last: the marching kernel with one-row chunks)
+                            4 * cdiv(nx, 224) * s.nyl,
+                            8 * cdiv((long)cdiv(nx, 48) * cdiv(s.nyl, 16), 4)}) + 8;   // (last two: the marching kernels with small chunks)
   for (int i = 0; i < 2; ++i) HIPC(hipMalloc((void**)&s.partials[i], sizeof(float) * s.partial_cap));
   s.scratch_cap = s.partial_cap;
   HIPC(hipMalloc((void**)&s.scratch_d, sizeof(double) * (s.scratch_cap + 8)));
@@ -399,7 +405,10 @@ void pick_defaults(lbm_ctx* c) {
   const char* e;
   if ((e = getenv("LBM_VECTOR_WIDTH"))) c->V = pick_vector_width(nx);
   if ((e = getenv("LBM_KERNEL_VARIANT"))) c->variant = atol(e) & 7;
-  if ((e = getenv("LBM_TIME_BLOCK"))) c->time_block = atoi(e) == 4 ? 4 : atoi(e) == 2 ? 2 : 1;
+  if ((e = getenv("LBM_TIME_BLOCK"))) { const int v = atoi(e); c->time_block = (v == 8 || v == 6 || v == 4 || v == 2) ? v : 1; }
+  if ((e = getenv("LBM_MARCH_KERNEL"))) c->march_kernel = atoi(e) == 0 ? 0 : 1;
+  if ((e = getenv("LBM_WAVE_ROWS")) && atoi(e) > 0) c->wave_rows = std::min(atoi(e), c->p.ny);
+  if ((e = getenv("LBM_MARCH_ROWS")) && atoi(e) > 0) c->march_rows = std::min(atoi(e), c->p.ny);
   if ((e = getenv("LBM_T2_THREADS"))) { const int t = atoi(e); if (t == 256 || t == 512 || t == 1024) c->t2_threads = t; }
 }
 
@@ -418,13 +427,14 @@ constexpr int kMarchK = 4;
 // The marching kernel runs on a lattice alone on its GPU (periodic wrap inside the kernel); its row
 // fetches are 16-byte LDS-DMA pieces, so columns must come in fours, and a strip is 256 columns wide.
 bool march_eligible(const lbm_ctx* c) {
-  return c->time_block == 4 && c->exchange == 0 && c->slabs.size() == 1 && c->p.nx % 4 == 0 &&
-         c->p.nx >= lbm::MarchCfg<kMarchK>::W && c->p.ny >= 2 * kMarchK &&
-         (double)c->p.ny * c->slabs[0].pitch * 4.0 < 4.0e9;   // 32-bit byte offsets inside a plane
+  if (c->time_block < 4 || c->exchange != 0 || c->slabs.size() != 1) return false;
+  if ((double)c->p.ny * c->slabs[0].pitch * 4.0 >= 4.0e9) return false;   // 32-bit byte offsets inside a plane
+  if (c->march_kernel == 1 || c->time_block != kMarchK)                    // lbm_wave: any width of at least one wave
+    return c->p.nx >= 64 && c->p.ny >= 2;
+  return c->p.nx % 4 == 0 && c->p.nx >= lbm::MarchCfg<kMarchK>::W && c->p.ny >= 2 * kMarchK;
 }
+inline bool use_wave_kernel(const lbm_ctx* c) { return c->march_kernel == 1 || c->time_block != kMarchK; }
 
-// Rows per chunk: every block pays 3 (K-1) fill iterations, and the grid should come out a little
-// under a whole number of rounds of one block per CU.
 // Useful rows over rows of time for chunks of h rows: `rounds` rounds of full-height blocks on every CU,
 // each paying its fill iterations.
 double march_efficiency(const lbm_ctx* c, int h) {
@@ -1125,6 +1135,81 @@ int launch_march(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev) {
   return LBM_OK;
 }
 
+// ---- lbm_wave: K steps per pass, one wave per 64-column strip
+template <int K>
+void launch_wave_k(const lbm_ctx* c, const lbm::WaveArgs& a, int grid, hipStream_t st) {
+  // flavours: IEEE or fast rcp/sqrt x nontemporal stores
+  switch ((int)(c->variant & (lbm::kFastMath | lbm::kNtStore))) {
+    case 0: hipLaunchKernelGGL((lbm::lbm_wave<K, 0>), dim3(grid), dim3(lbm::kWaveBlock), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((lbm::lbm_wave<K, 1>), dim3(grid), dim3(lbm::kWaveBlock), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((lbm::lbm_wave<K, 2>), dim3(grid), dim3(lbm::kWaveBlock), 0, st, a); break;
+    default: hipLaunchKernelGGL((lbm::lbm_wave<K, 3>), dim3(grid), dim3(lbm::kWaveBlock), 0, st, a); break;
+  }
+}
+
+template <int K>
+int wave_blocks_per_cu() {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, lbm::lbm_wave<K, 1>, lbm::kWaveBlock, 0) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+  return n;
+}
+
+// Waves the device holds at once, and the rows per chunk that use them best: all waves resident in one
+// round where the lattice allows it (each chunk pays 2K fill iterations), whole rounds otherwise.
+void wave_plan(lbm_ctx* c) {
+  const int K = c->time_block;
+  int bpc = (K == 8) ? wave_blocks_per_cu<8>() : (K == 6) ? wave_blocks_per_cu<6>() : wave_blocks_per_cu<4>();
+  if (bpc < 1) bpc = 4;
+  c->wave_capacity = std::max(c->ncu, 1) * bpc * (lbm::kWaveBlock / 64);
+  if (c->wave_rows > 0) return;
+  const int nwc = cdiv(c->p.nx, 64 - 2 * K), ny = c->p.ny;
+  const double cap = (double)c->wave_capacity;
+  int best_h = std::min(ny, 128);
+  double best = -1.0;
+  for (int h = std::min(ny, 16); h <= std::min(ny, 2048); ++h) {
+    const double waves = (double)nwc * cdiv(ny, h);
+    const double fill = (double)h / (double)(h + 2 * K);
+    double eff;
+    if (waves <= cap) eff = std::min(1.0, waves / (0.6 * cap)) * fill;      // (a SIMD is busy from about 60 % of its wave slots)
+    else { const double rounds = std::ceil(waves / cap); eff = waves / (rounds * cap) * fill; }
+    if (eff > best + 1e-9) { best = eff; best_h = h; }
+  }
+  c->wave_rows = best_h;
+}
+
+// One lbm_wave launch: steps tt .. tt+K-1 of the lone slab, launch index li.
+int launch_wave(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev) {
+  Slab& s = c->slabs[0];
+  HIPC(hipSetDevice(s.dev));
+  const int K = c->time_block;
+  if (c->wave_rows <= 0 || c->wave_capacity <= 0) wave_plan(c);
+  const int q = li & 1, qp = q ^ 1;
+  lbm::WaveArgs a;
+  a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
+  a.plane = s.plane; a.pitch = s.pitch; a.nx = c->p.nx; a.ny = c->p.ny;
+  a.blocked = s.blocked; a.omega = c->p.omega;
+  a.accel_row = c->p.ny - 2; a.accel_out = accel_out ? 1 : 0;
+  a.a1 = c->p.density * c->p.accel / 9.f; a.a2 = c->p.density * c->p.accel / 36.f;
+  a.H = c->wave_rows;
+  a.nwc = cdiv(c->p.nx, 64 - 2 * K); a.nchunks = cdiv(c->p.ny, a.H);
+  const int nb = cdiv((long)a.nwc * a.nchunks, lbm::kWaveBlock / 64);
+  if ((long)K * nb > s.partial_cap) return fail(LBM_EINVAL, "lbm_wave: %d blocks exceed the partial-sum buffer (raise wave_rows)", nb);
+  a.partials = s.partials[q];
+  a.prev = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
+  if (fold_prev) { a.prev = s.partials[qp]; a.prev_count = nb; a.prev_sum = s.sums + (tt - K); }
+  switch (K) {
+    case 8: launch_wave_k<8>(c, a, nb, s.sc); break;
+    case 6: launch_wave_k<6>(c, a, nb, s.sc); break;
+    default: launch_wave_k<4>(c, a, nb, s.sc); break;
+  }
+  HIPC(hipGetLastError());
+  c->cur ^= 1;
+  return LBM_OK;
+}
+inline int wave_blocks(const lbm_ctx* c) {
+  return cdiv((long)cdiv(c->p.nx, 64 - 2 * c->time_block) * cdiv(c->p.ny, c->wave_rows), lbm::kWaveBlock / 64);
+}
+
 }  // namespace
 
 namespace {
@@ -1507,14 +1592,15 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
   // Launch index li numbers the launch groups (a pair of steps or a single step); its parity
   // selects the halo / partial-sum buffers.
   int li = 0, tt = 0;
-  if (march_eligible(c) && nsteps >= kMarchK) {   // groups of K steps, row-marching (lone slab)
-    const int ngroups = nsteps / kMarchK;
-    for (int g = 0; g < ngroups; ++g, ++li, tt += kMarchK)
-      if ((rc = launch_march(c, li, tt, tt + kMarchK < nsteps, g > 0))) return rc;
+  if (march_eligible(c) && nsteps >= c->time_block) {   // groups of K steps, row-marching (lone slab)
+    const int K = c->time_block, ngroups = nsteps / K;
+    const bool wave = use_wave_kernel(c);
+    for (int g = 0; g < ngroups; ++g, ++li, tt += K)
+      if ((rc = wave ? launch_wave(c, li, tt, tt + K < nsteps, g > 0) : launch_march(c, li, tt, tt + K < nsteps, g > 0))) return rc;
     Slab& s = c->slabs[0];
-    const int nb = cdiv(nx, lbm::MarchCfg<kMarchK>::WOUT) * cdiv(c->p.ny, c->march_rows);
-    hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(kMarchK), dim3(lbm::kBlock), 0, s.sc, s.partials[(li - 1) & 1], nb,
-                       s.sums + (tt - kMarchK), nb);
+    const int nb = wave ? wave_blocks(c) : cdiv(nx, lbm::MarchCfg<kMarchK>::WOUT) * cdiv(c->p.ny, c->march_rows);
+    hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(K), dim3(lbm::kBlock), 0, s.sc, s.partials[(li - 1) & 1], nb,
+                       s.sums + (tt - K), nb);
     HIPC(hipGetLastError());
   }
   if (pairs && nsteps - tt >= 2) {
@@ -1695,8 +1781,19 @@ extern "C" int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     c->march_rows = (int)value;
     return LBM_OK;
   }
+  if (!strcmp(key, "march_kernel")) {
+    if (value != 0 && value != 1) return fail(LBM_EINVAL, "march_kernel must be 0 (lbm_march) or 1 (lbm_wave)");
+    c->march_kernel = (int)value;
+    return LBM_OK;
+  }
+  if (!strcmp(key, "wave_rows")) {
+    if (value < 1 || value > c->p.ny) return fail(LBM_EINVAL, "wave_rows must be in [1, ny]");
+    c->wave_rows = (int)value;
+    return LBM_OK;
+  }
   if (!strcmp(key, "time_block")) {
-    if (value != 1 && value != 2 && value != 4) return fail(LBM_EINVAL, "time_block must be 1, 2 or 4");
+    if (value != 1 && value != 2 && value != 4 && value != 6 && value != 8) return fail(LBM_EINVAL, "time_block must be 1, 2, 4, 6 or 8");
+    if (value != c->time_block) { c->wave_rows = 0; c->wave_capacity = 0; }
     c->time_block = (int)value;
     c->engine = 1;
     return LBM_OK;
@@ -1731,7 +1828,10 @@ extern "C" int lbm_get_info(const lbm_ctx* c, const char* key, double* value) {
   if (!strcmp(key, "kernel_variant")) { *value = (double)c->variant; return LBM_OK; }
   if (!strcmp(key, "time_block")) { *value = c->time_block; return LBM_OK; }
   if (!strcmp(key, "t2_threads")) { *value = c->t2_threads; return LBM_OK; }
-  if (!strcmp(key, "time_block_active")) { *value = march_eligible(c) ? 4 : t2_eligible(c) ? 2 : 1; return LBM_OK; }
+  if (!strcmp(key, "time_block_active")) { *value = march_eligible(c) ? c->time_block : t2_eligible(c) ? 2 : 1; return LBM_OK; }
+  if (!strcmp(key, "march_kernel")) { *value = (march_eligible(c) && use_wave_kernel(c)) ? 1 : 0; return LBM_OK; }
+  if (!strcmp(key, "wave_rows")) { *value = c->wave_rows; return LBM_OK; }
+  if (!strcmp(key, "wave_capacity")) { *value = c->wave_capacity; return LBM_OK; }
   if (!strcmp(key, "march_rows")) { *value = c->march_rows > 0 ? c->march_rows : march_pick_rows(c); return LBM_OK; }
   if (!strcmp(key, "fluid_cells")) { *value = (double)c->tot_fluid; return LBM_OK; }
   if (!strcmp(key, "engine")) { *value = c->engine; return LBM_OK; }

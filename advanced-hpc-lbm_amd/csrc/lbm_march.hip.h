@@ -292,9 +292,13 @@ __global__ __launch_bounds__(K * 256) void lbm_march(const MarchArgs a) {
 
   // block -> (strip, chunk): XCD-aware (block ids are dealt round-robin over the 8 XCDs; give each a
   // contiguous run, so strips that share halo columns mostly share an L2)
-  int b = blockIdx.x;
   const int nb = gridDim.x;
-  if ((nb & 7) == 0) b = (b & 7) * (nb >> 3) + (b >> 3);
+  int b;
+  {
+    // bijective for any grid size: XCD x (= blockIdx % 8) gets q+1 items if x < r, else q  (q = nb / 8, r = nb % 8)
+    const int x = blockIdx.x & 7, i = blockIdx.x >> 3, q = nb >> 3, r = nb & 7;
+    b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
   const int chunk = b / a.nstrips, strip = b - chunk * a.nstrips;
   MarchGeom g;
   g.X0 = strip * C::WOUT; g.Y0 = chunk * a.H;

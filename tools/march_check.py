@@ -24,23 +24,24 @@ def random_case(nx, ny, seed, blocked=0.1):
     return p, ob, cells
 
 
-def compare(nx, ny, rows, steps_list, seed=1):
+def compare(nx, ny, rows, steps_list, seed=1, tb=4, kernel=0):
     p, ob, cells = random_case(nx, ny, seed)
     with L.Lattice(p, ob, cells) as a:
         a.set_option("time_block", 1)
         av_a = np.concatenate([a.run(n) for n in steps_list])
         st_a = a.read_state()
     with L.Lattice(p, ob, cells) as b:
-        b.set_option("time_block", 4)
+        b.set_option("march_kernel", kernel)
+        b.set_option("time_block", tb)
         if rows:
-            b.set_option("march_rows", rows)
-        assert int(b.info("time_block_active")) == 4, "marching kernel not eligible"
+            b.set_option("wave_rows" if kernel else "march_rows", rows)
+        assert int(b.info("time_block_active")) == tb, "marching kernel not eligible"
         av_b = np.concatenate([b.run(n) for n in steps_list])
         st_b = b.read_state()
-        rows_used = int(b.info("march_rows"))
+        rows_used = int(b.info("wave_rows" if kernel else "march_rows"))
     same = np.array_equal(st_a.view(np.uint32), st_b.view(np.uint32))
     avok = np.allclose(av_a, av_b, rtol=2e-6, atol=0)
-    msg = f"{nx}x{ny} rows/chunk {rows_used} steps {steps_list}: state {'BIT-EXACT' if same else 'DIFFERS'}, av_vels {'ok' if avok else 'DIFFER'}"
+    msg = f"{'lbm_wave' if kernel else 'lbm_march'}<{tb}> {nx}x{ny} rows/chunk {rows_used} steps {steps_list}: state {'BIT-EXACT' if same else 'DIFFERS'}, av_vels {'ok' if avok else 'DIFFER'}"
     if not same:
         d = np.argwhere(st_a.view(np.uint32) != st_b.view(np.uint32))
         msg += f"  [{len(d)} values differ; first (y,x,k) = {d[:5].tolist()}; planes {sorted(set(d[:, 2].tolist()))}; " \
@@ -52,21 +53,23 @@ def compare(nx, ny, rows, steps_list, seed=1):
     return same and avok
 
 
-def timing(n, steps, tbs=(2, 4), rows=None):
+def timing(n, steps, tbs=(2, 4), rows=None, kernel=0, form=0):
     p = L.Param(n, n, 1000, 10, 0.1, 0.01, 1.85)
     ob = obstacle_map(n, n)
     for tb in tbs:
         with L.Lattice(p, ob) as lat:
+            lat.set_option("march_kernel", kernel)
             lat.set_option("time_block", tb)
-            if tb == 4 and rows:
-                lat.set_option("march_rows", rows)
+            if tb >= 4 and rows:
+                lat.set_option("wave_rows" if kernel else "march_rows", rows)
             lat.run(steps)
             best = 1e9
             for _ in range(3):
                 lat.run(steps)
                 g, w = lat.last_run_ms()
                 best = min(best, g)
-            print(f"{n}x{n} time_block {tb} (active {int(lat.info('time_block_active'))}, rows {int(lat.info('march_rows'))}): "
+            print(f"{n}x{n} time_block {tb} kernel {kernel} form {form} (active {int(lat.info('time_block_active'))}, rows {int(lat.info('wave_rows' if kernel else 'march_rows'))}, "
+                  f"capacity {int(lat.info('wave_capacity'))}): "
                   f"{best * 1e3 / steps:.2f} us/step, {n * n * steps / best / 1e6:.1f} GLUPS", flush=True)
 
 
@@ -83,14 +86,26 @@ def main():
         except (L.LbmError, AssertionError) as e:
             print(f"{nx}x{ny} rows {rows}: ERROR {e}", flush=True)
             ok = False
+    wcases = [(64, 40, 0, [4]), (100, 30, 7, [8, 5]), (130, 77, 16, [13])] + cases[4:]
+    for tb in (4, 6, 8):
+        for nx, ny, rows, steps in wcases:
+            steps = [n * tb // 4 + (1 if n % 4 else 0) for n in steps]
+            try:
+                ok &= compare(nx, ny, rows, steps, tb=tb, kernel=1)
+            except (L.LbmError, AssertionError) as e:
+                print(f"lbm_wave<{tb}> {nx}x{ny} rows {rows}: ERROR {e}", flush=True)
+                ok = False
     print("ALL BIT-EXACT" if ok else "MISMATCHES", flush=True)
     if not quick:
-        timing(8192, 80)
-        timing(4096, 160)
-        timing(2048, 400)
-        timing(1024, 2000)
-        for rows in (128, 192, 304, 512):
-            timing(8192, 80, tbs=(4,), rows=rows)
+        timing(8192, 96, tbs=(2, 4))
+        for rows in (24, 32, 48, 64, 96):
+            timing(8192, 96, tbs=(4, 6, 8), rows=rows, kernel=1)
+        for rows in (32, 64):
+            timing(8192, 96, tbs=(4, 6, 8), rows=rows, kernel=1, form=1)
+        for rows in (32, 64):
+            timing(4096, 192, tbs=(4, 6, 8), rows=rows, kernel=1)
+            timing(2048, 384, tbs=(4, 6, 8), rows=rows, kernel=1)
+            timing(1024, 1920, tbs=(4, 6, 8), rows=rows, kernel=1)
     return 0 if ok else 1
 
 
