@@ -175,8 +175,10 @@ struct lbm_ctx {
                                // 4: four steps per pass, row-marching (lbm_march), where eligible, then 2, then 1
   int t2_threads = 256;        // threads per tile of the two-step kernel (256 / 512 / 1024)
   int march_rows = 0;          // rows per chunk of the marching kernel (lbm_march, time_block = 4); 0 = not chosen yet
-  int march_kernel = 1;        // which marching kernel runs time_block >= 4: 0 = lbm_march (one block per strip, LDS rings,
-                               // K = 4 only), 1 = lbm_wave (one wave per strip, register pipeline, K = 4 / 6 / 8)
+  int march_kernel = -1;       // which marching kernel runs time_block >= 4: 0 = lbm_march (one block per strip, LDS rings,
+                               // K = 4, widths that are multiples of 4 from 256 up), 1 = lbm_wave (one wave per strip,
+                               // register pipeline, K = 4 / 6 / 8, any width from 64 up), -1 = lbm_march where it can run
+                               // (269 GLUPS at 8192^2 against 262 for lbm_wave<8>), lbm_wave elsewhere
   int wave_rows = 0;           // rows per chunk of lbm_wave; 0 = not chosen yet
   int wave_capacity = 0;       // waves of lbm_wave<time_block> the device holds at once (occupancy query)
   uint32_t seq = 0;            // peer-to-peer: sequence number of the last launch group (same on all slabs)
@@ -406,7 +408,7 @@ void pick_defaults(lbm_ctx* c) {
   if ((e = getenv("LBM_VECTOR_WIDTH"))) c->V = pick_vector_width(nx);
   if ((e = getenv("LBM_KERNEL_VARIANT"))) c->variant = atol(e) & 7;
   if ((e = getenv("LBM_TIME_BLOCK"))) { const int v = atoi(e); c->time_block = (v == 8 || v == 6 || v == 4 || v == 2) ? v : 1; }
-  if ((e = getenv("LBM_MARCH_KERNEL"))) c->march_kernel = atoi(e) == 0 ? 0 : 1;
+  if ((e = getenv("LBM_MARCH_KERNEL"))) c->march_kernel = atoi(e) == 0 ? 0 : atoi(e) == 1 ? 1 : -1;
   if ((e = getenv("LBM_WAVE_ROWS")) && atoi(e) > 0) c->wave_rows = std::min(atoi(e), c->p.ny);
   if ((e = getenv("LBM_MARCH_ROWS")) && atoi(e) > 0) c->march_rows = std::min(atoi(e), c->p.ny);
   if ((e = getenv("LBM_T2_THREADS"))) { const int t = atoi(e); if (t == 256 || t == 512 || t == 1024) c->t2_threads = t; }
@@ -426,14 +428,16 @@ constexpr int kMarchK = 4;
 
 // The marching kernel runs on a lattice alone on its GPU (periodic wrap inside the kernel); its row
 // fetches are 16-byte LDS-DMA pieces, so columns must come in fours, and a strip is 256 columns wide.
+inline bool march_block_ok(const lbm_ctx* c) {   // lbm_march's own requirements
+  return c->time_block == kMarchK && c->p.nx % 4 == 0 && c->p.nx >= lbm::MarchCfg<kMarchK>::W && c->p.ny >= 2 * kMarchK;
+}
+inline bool use_wave_kernel(const lbm_ctx* c) { return c->march_kernel == 1 || (c->march_kernel < 0 && !march_block_ok(c)); }
 bool march_eligible(const lbm_ctx* c) {
   if (c->time_block < 4 || c->exchange != 0 || c->slabs.size() != 1) return false;
   if ((double)c->p.ny * c->slabs[0].pitch * 4.0 >= 4.0e9) return false;   // 32-bit byte offsets inside a plane
-  if (c->march_kernel == 1 || c->time_block != kMarchK)                    // lbm_wave: any width of at least one wave
-    return c->p.nx >= 64 && c->p.ny >= 2;
-  return c->p.nx % 4 == 0 && c->p.nx >= lbm::MarchCfg<kMarchK>::W && c->p.ny >= 2 * kMarchK;
+  if (use_wave_kernel(c)) return c->p.nx >= 64 && c->p.ny >= 2;           // lbm_wave: any width of at least one wave
+  return march_block_ok(c);
 }
-inline bool use_wave_kernel(const lbm_ctx* c) { return c->march_kernel == 1 || c->time_block != kMarchK; }
 
 // Useful rows over rows of time for chunks of h rows: `rounds` rounds of full-height blocks on every CU,
 // each paying its fill iterations.
@@ -657,7 +661,10 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
     // below (2048^2: 88 %).
     if (!getenv("LBM_TIME_BLOCK") && c->time_block == 2) {
       c->time_block = 4;
-      if (!march_eligible(c) || march_efficiency(c, march_pick_rows(c)) < 0.65) c->time_block = 2;
+      if (!march_eligible(c)) c->time_block = 2;
+      else if (!use_wave_kernel(c)) { if (march_efficiency(c, march_pick_rows(c)) < 0.65) c->time_block = 2; }
+      else if ((long)c->p.nx * c->p.ny < (3L << 20)) c->time_block = 2;   // lbm_wave needs a few thousand waves: from about 2048^2
+      else c->time_block = 6;
     }
   }
   return LBM_OK;
@@ -1154,27 +1161,17 @@ int wave_blocks_per_cu() {
   return n;
 }
 
-// Waves the device holds at once, and the rows per chunk that use them best: all waves resident in one
-// round where the lattice allows it (each chunk pays 2K fill iterations), whole rounds otherwise.
+// Waves the device holds at once (occupancy query), and the rows per chunk.  Short chunks win although each
+// pays 2K fill iterations: many more waves than the device holds keep every SIMD's wave slots full from the
+// first row to the last (measured at 8192^2, GLUPS for 24 / 32 / 48 / 64 / 96 rows: K = 4: 193 219 191 204 179;
+// K = 6: 229 237 244 246 237; K = 8: 198 212 224 227 228; one resident round of 511-row chunks: 153 at K = 4).
 void wave_plan(lbm_ctx* c) {
   const int K = c->time_block;
   int bpc = (K == 8) ? wave_blocks_per_cu<8>() : (K == 6) ? wave_blocks_per_cu<6>() : wave_blocks_per_cu<4>();
   if (bpc < 1) bpc = 4;
   c->wave_capacity = std::max(c->ncu, 1) * bpc * (lbm::kWaveBlock / 64);
   if (c->wave_rows > 0) return;
-  const int nwc = cdiv(c->p.nx, 64 - 2 * K), ny = c->p.ny;
-  const double cap = (double)c->wave_capacity;
-  int best_h = std::min(ny, 128);
-  double best = -1.0;
-  for (int h = std::min(ny, 16); h <= std::min(ny, 2048); ++h) {
-    const double waves = (double)nwc * cdiv(ny, h);
-    const double fill = (double)h / (double)(h + 2 * K);
-    double eff;
-    if (waves <= cap) eff = std::min(1.0, waves / (0.6 * cap)) * fill;      // (a SIMD is busy from about 60 % of its wave slots)
-    else { const double rounds = std::ceil(waves / cap); eff = waves / (rounds * cap) * fill; }
-    if (eff > best + 1e-9) { best = eff; best_h = h; }
-  }
-  c->wave_rows = best_h;
+  c->wave_rows = std::min(c->p.ny, K >= 8 ? 96 : K >= 6 ? 64 : 32);
 }
 
 // One lbm_wave launch: steps tt .. tt+K-1 of the lone slab, launch index li.
@@ -1782,7 +1779,7 @@ extern "C" int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     return LBM_OK;
   }
   if (!strcmp(key, "march_kernel")) {
-    if (value != 0 && value != 1) return fail(LBM_EINVAL, "march_kernel must be 0 (lbm_march) or 1 (lbm_wave)");
+    if (value < -1 || value > 1) return fail(LBM_EINVAL, "march_kernel must be 0 (lbm_march), 1 (lbm_wave) or -1 (automatic)");
     c->march_kernel = (int)value;
     return LBM_OK;
   }

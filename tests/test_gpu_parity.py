@@ -93,8 +93,8 @@ def test_fifty_steps_against_float_oracle(gpu, O, oracle, deck):
     # 7 = that + nontemporal loads and stores (the flavours the library picks by lattice size)
     # (time_block 1 = the one-step kernel lbm_sweep<V>, which is what V selects; 2 = lbm_sweep2, where
     # the flavour bits still apply)
-    # (time_block 1 = the one-step kernel lbm_sweep<V>, which is what V selects; 2 = lbm_sweep2 and 4 = lbm_march
-    # (lattices of at least 256 columns; else it falls back to 2), where the flavour bits still apply)
+    # (time_block 1 = the one-step kernel lbm_sweep<V>, which is what V selects; 2 = lbm_sweep2, 4 = lbm_march or,
+    # on lattices narrower than 256 columns, lbm_wave<4>; the flavour bits apply to all of them)
     combos = [(1, V, variant) for V in (4, 2, 1) for variant in (0, 1, 6, 7)] + [(2, 4, 0), (2, 4, 1), (2, 4, 3),
                                                                                   (4, 4, 0), (4, 4, 1), (4, 4, 3)]
     for tb, V, variant in combos:
@@ -103,7 +103,7 @@ def test_fifty_steps_against_float_oracle(gpu, O, oracle, deck):
             lat.set_option("vector_width", V)
             lat.set_option("kernel_variant", variant)
             assert lat.info("vector_width") == V and lat.info("kernel_variant") == variant
-            assert lat.info("time_block_active") == (tb if tb < 4 or p.nx >= 256 else 2)
+            assert lat.info("time_block_active") == tb        # (4: lbm_march from 256 columns up, lbm_wave<4> on the 128-wide decks)
             av = lat.run(50)
             st = lat.read_state()
             fs = lat.final_state()
@@ -831,11 +831,40 @@ def test_marching_kernel_equals_single_step_kernel(gpu, nx, ny, rows, steps):
         av_a = np.concatenate([a.run(n) for n in steps])
         st_a = a.read_state()
     with L.Lattice(p, ob, cells) as b:
+        b.set_option("march_kernel", 0)
         b.set_option("time_block", 4)
         if rows:
             b.set_option("march_rows", rows)
-        assert b.info("time_block_active") == 4
+        assert b.info("time_block_active") == 4 and b.info("march_kernel") == 0
         av_b = np.concatenate([b.run(n) for n in steps])
+        st_b = b.read_state()
+    assert np.array_equal(st_a.view(np.uint32), st_b.view(np.uint32))
+    assert np.allclose(av_a, av_b, rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("K", [4, 6, 8])
+@pytest.mark.parametrize("nx,ny,rows,steps", [
+    (64, 40, 0, [1, 0]), (100, 30, 7, [2, 1]), (130, 77, 16, [3, 1]),        # one wave column; widths that are no multiple of 4
+    (480, 70, 0, [3, 2]), (1000, 24, 8, [2, 3]), (1024, 1024, 0, [4, 3]),     # steps = groups of K (+ a remainder)
+])
+def test_wave_marching_kernel_equals_single_step_kernel(gpu, K, nx, ny, rows, steps):
+    """lbm_wave<K> (K steps per pass, one wave per 64-column strip, the time skew in registers, whole-wave DPP
+    shifts for the neighbouring columns) against the one-step kernel: bit-identical lattice, av_vels within
+    summation order; groups of K steps plus remainders through lbm_sweep2 / lbm_sweep."""
+    L = gpu
+    p, ob, cells = _random_case(L, nx, ny, 3)
+    runs = [steps[0] * K + steps[1], K]
+    with L.Lattice(p, ob, cells) as a:
+        a.set_option("time_block", 1)
+        av_a = np.concatenate([a.run(n) for n in runs])
+        st_a = a.read_state()
+    with L.Lattice(p, ob, cells) as b:
+        b.set_option("march_kernel", 1)
+        b.set_option("time_block", K)
+        if rows:
+            b.set_option("wave_rows", rows)
+        assert b.info("time_block_active") == K and b.info("march_kernel") == 1
+        av_b = np.concatenate([b.run(n) for n in runs])
         st_b = b.read_state()
     assert np.array_equal(st_a.view(np.uint32), st_b.view(np.uint32))
     assert np.allclose(av_a, av_b, rtol=2e-6, atol=0)
@@ -849,10 +878,16 @@ def test_marching_kernel_is_the_default_on_big_lattices_only(gpu):
         p = L.Param(n, n, 10, 10, 0.1, 0.01, 1.85)
         with L.Lattice(p, np.zeros((n, n), dtype=np.int32)) as lat:
             assert lat.info("time_block_active") == want, n
-    p = L.Param(128, 4096, 10, 10, 0.1, 0.01, 1.85)
-    with L.Lattice(p, np.zeros((4096, 128), dtype=np.int32)) as lat:
+            assert lat.info("march_kernel") == 0                   # lbm_march wherever it can run
+    # a width lbm_march cannot take (not a multiple of 4): lbm_wave<6> on a big lattice
+    p = L.Param(2050, 2048, 10, 10, 0.1, 0.01, 1.85)
+    with L.Lattice(p, np.zeros((2048, 2050), dtype=np.int32)) as lat:
+        assert lat.info("time_block_active") == 6 and lat.info("march_kernel") == 1
+    # narrower than one wave: no marching kernel at all
+    p = L.Param(48, 4096, 10, 10, 0.1, 0.01, 1.85)
+    with L.Lattice(p, np.zeros((4096, 48), dtype=np.int32)) as lat:
         lat.set_option("time_block", 4)
-        assert lat.info("time_block_active") == 2
+        assert lat.info("time_block_active") == 1
 
 
 @pytest.mark.parametrize("tile,nx,ny,steps", [

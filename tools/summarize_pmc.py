@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, wl, fdir, wdir = sys.argv[1:5]
 nx, ny = (int(v) for v in wl.split("x"))
 cells = nx * ny
-STEPS = {"lbm_march": 4, "lbm_sweep2": 2, "lbm_sweep": 1}
+STEPS = {"lbm_march": 4, "lbm_sweep2": 2, "lbm_sweep": 1, "lbm_wave4": 4, "lbm_wave6": 6, "lbm_wave8": 8}
 vals = collections.defaultdict(dict)
 for which, d in (("FETCH_SIZE", fdir), ("WRITE_SIZE", wdir)):
     f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
@@ -26,7 +26,10 @@ for which, d in (("FETCH_SIZE", fdir), ("WRITE_SIZE", wdir)):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != which:
             continue
-        kern = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("lbm::", "").split("<")[0]
+        full = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("lbm::", "")
+        kern = full.split("<")[0]
+        if kern == "lbm_wave":
+            kern += full.split("<")[1].split(",")[0].strip()
         if kern in STEPS:
             agg[(kern, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
     for kern in STEPS:
