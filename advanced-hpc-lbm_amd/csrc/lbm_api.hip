@@ -35,6 +35,7 @@
 #include "lbm_resident.hip.h"
 #include "lbm_march.hip.h"
 #include "lbm_wave.hip.h"
+#include "lbm_regtile.hip.h"
 
 // ----------------------------------------------------------------- errors
 static thread_local char g_err[1024] = "";
@@ -186,15 +187,19 @@ struct lbm_ctx {
   bool no_comm = false;        // rank mode without RCCL: results are this rank's contribution
   bool p2p_failed = false;     // a peer-to-peer halo wait timed out: the lattice is no longer defined
   // engine: which kernel family lbm_run uses for a lattice alone on its GPU
-  //   0 auto = whichever measured faster (today: the streaming kernels everywhere -- the resident
-  //   kernel is bit-identical but its per-step hand-off costs more than it saves),
-  //   1 streaming only (lbm_sweep2 / lbm_sweep), 2 resident (lbm_resident) or fail
+  //   0 auto = the register-resident kernel (lbm_regtile) where the lattice tiles onto the CUs (the four
+  //   shipped decks: 1.5-2x the streaming kernels), the streaming kernels elsewhere,
+  //   1 streaming only (lbm_sweep2 / lbm_sweep), 2 resident in LDS (lbm_resident) or fail,
+  //   3 resident in registers (lbm_regtile) or fail
   int engine = 0;
   int engine_last = 0;         // what the last lbm_run used: 1 streaming, 2 resident
   struct { int tx = 0, ty = 0, v = 0, threads = 0, ntx = 0, nty = 0; } rplan;   // resident tiling (tx == 0: none)
+  struct { int ty = 0, r = 0, nw = 0, ntx = 0, nty = 0; } tplan;   // register-tile engine (engine 3): 64 x ty tiles, nw waves of r rows (ty == 0: none)
+  unsigned long long* tmail = nullptr;   // its mailboxes
   unsigned long long* rmail = nullptr;   // resident mailboxes
   float* rpartials = nullptr;  // [steps][tiles]
   long rpartials_cap = 0;      // in steps
+  int rpartials_tiles = 0;     // tiles per step it was sized for
   uint32_t* rabort = nullptr;  // device abort word of the resident kernel
   uint32_t rtag = 1;           // next unused mailbox tag (0 = never written)
   bool resident_broken = false;   // a resident run gave up on this device: stay with the streaming kernels
@@ -633,7 +638,8 @@ int ensure_sums(Slab& s, int nsteps) {
   return LBM_OK;
 }
 
-bool plan_resident(lbm_ctx* c);   // resident engine, below
+bool plan_resident(lbm_ctx* c);   // resident engines, below
+bool plan_regtile(lbm_ctx* c);
 
 int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
   const bool exchanging = c->exchange != 0;
@@ -653,8 +659,8 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
     if (hipGetDeviceProperties(&prop, c->slabs[0].dev) == hipSuccess) c->ncu = prop.multiProcessorCount;
     else (void)hipGetLastError();
     const char* e = getenv("LBM_ENGINE");
-    if (e) c->engine = (atoi(e) >= 0 && atoi(e) <= 2) ? atoi(e) : 0;
-    if (!exchanging && c->slabs.size() == 1) plan_resident(c);
+    if (e) c->engine = (atoi(e) >= 0 && atoi(e) <= 3) ? atoi(e) : 0;
+    if (!exchanging && c->slabs.size() == 1) { plan_resident(c); plan_regtile(c); }
     // Four steps per pass (lbm_march) where its strips and chunks fill the chip: measured 1.5-1.6x
     // lbm_sweep2 from 2048^2 up (194 / 226 / 238 GLUPS at 2048^2 / 4096^2 / 8192^2 against 129 / 146 /
     // 150), 0.8x at 1024^2, where 5 strips x 32-row chunks leave the CUs 49 % busy by the estimate
@@ -1305,6 +1311,8 @@ void resident_free(lbm_ctx* c) {
   if (c->slabs.empty()) return;
   (void)hipSetDevice(c->slabs[0].dev);
   if (c->rmail) (void)hipFree(c->rmail);
+  if (c->tmail) (void)hipFree(c->tmail);
+  c->tmail = nullptr; c->rpartials_tiles = 0;
   if (c->rpartials) (void)hipFree(c->rpartials);
   if (c->rabort) (void)hipFree(c->rabort);
   c->rmail = nullptr; c->rpartials = nullptr; c->rabort = nullptr; c->rpartials_cap = 0;
@@ -1342,13 +1350,14 @@ int run_resident(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
     HIPC(hipMemsetAsync(c->rmail, 0, mail_bytes, s.sc));
     c->rtag = 1;
   }
-  if (c->rpartials_cap < nsteps) {
+  if (c->rpartials_cap < nsteps || c->rpartials_tiles < ntiles) {
     long cap = std::max(1024L, c->rpartials_cap);
     while (cap < nsteps) cap *= 2;
     if (c->rpartials) HIPC(hipFree(c->rpartials));
     c->rpartials = nullptr; c->rpartials_cap = 0;
-    HIPC(hipMalloc((void**)&c->rpartials, sizeof(float) * (size_t)cap * ntiles));
-    c->rpartials_cap = cap;
+    const int tiles = std::max(ntiles, c->rpartials_tiles);
+    HIPC(hipMalloc((void**)&c->rpartials, sizeof(float) * (size_t)cap * tiles));
+    c->rpartials_cap = cap; c->rpartials_tiles = tiles;
   }
   int rc = ensure_sums(s, nsteps);
   if (rc) return rc;
@@ -1385,6 +1394,110 @@ int run_resident(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
     HIPC(hipMemsetAsync(c->rabort, 0, 64, s.sc));
     HIPC(hipStreamSynchronize(s.sc));
     if (getenv("LBM_VERBOSE")) fprintf(stderr, "lbm: the resident kernel gave up (a tile was not scheduled); using the streaming kernels\n");
+    return LBM_OK;
+  }
+  c->cur ^= 1;
+  *done = true;
+  return LBM_OK;
+}
+
+// ---- register-tile engine (lbm_regtile.hip.h): 64-column tiles of nw x r rows, one per CU
+bool regtile_ok(const lbm_ctx* c, int ty, int r) {
+  if (c->p.nx % 64 != 0 || ty < 1 || ty > c->p.ny || c->p.ny % ty != 0) return false;
+  if (!(r == 1 || r == 2 || r == 4) || ty % r != 0 || ty / r > 16) return false;
+  // every tile must be resident at once: a CU takes 16 waves of this kernel (128 VGPRs) and three of its 49-KB LDS blocks
+  const int per_cu = std::min(3, 16 / (ty / r));
+  return (long)(c->p.nx / 64) * (c->p.ny / ty) <= (long)c->ncu * per_cu;
+}
+void regtile_set(lbm_ctx* c, int ty, int r) {
+  c->tplan.ty = ty; c->tplan.r = r; c->tplan.nw = ty / r; c->tplan.ntx = c->p.nx / 64; c->tplan.nty = c->p.ny / ty;
+}
+// Default tiling.  A step is bounded by the hand-off with the neighbouring tiles (about 1.6 us) plus the serial
+// work of one wave, so: as few rows per wave as the lattice allows (1, then 2, then 4), and tiles of several
+// waves (they trade rows through LDS, not through mailboxes) on at most half the CUs where that is possible.
+// Measured, us per step: 128^2 1.63 (2 waves x 1 row; 256 one-wave tiles: 2.09), 256^2 2.02 (4 x 1), 1024^2 5.05
+// (16 x 4, the only shape that fits one block per CU; two 8-wave blocks per CU: 4.95).
+bool plan_regtile(lbm_ctx* c) {
+  c->tplan.ty = 0;
+  const long ntx = c->p.nx / 64;
+  for (long limit : {(long)c->ncu / 2, (long)c->ncu})
+    for (int r : {1, 2, 4})
+      for (int ty = r; ty <= std::min(c->p.ny, 16 * r); ty += r)
+        if (regtile_ok(c, ty, r) && ntx * (c->p.ny / ty) <= limit) { regtile_set(c, ty, r); return true; }
+  return false;
+}
+
+int run_regtile(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
+  *done = false;
+  Slab& s = c->slabs[0];
+  HIPC(hipSetDevice(s.dev));
+  const auto& t = c->tplan;
+  const int ntiles = t.ntx * t.nty;
+  const size_t mail_bytes = sizeof(unsigned long long) * (size_t)ntiles * 2 * (size_t)lbm::regtile_box(t.ty);
+  if (!c->tmail) {
+    HIPC(hipMalloc((void**)&c->tmail, mail_bytes));
+    HIPC(hipMemsetAsync(c->tmail, 0, mail_bytes, s.sc));
+    if (!c->rabort) {
+      HIPC(hipMalloc((void**)&c->rabort, 64));
+      HIPC(hipMemsetAsync(c->rabort, 0, 64, s.sc));
+    }
+  }
+  if ((unsigned long long)c->rtag + (unsigned long long)nsteps >= 0x7fffff00ull) {   // tags would wrap: start over
+    HIPC(hipMemsetAsync(c->tmail, 0, mail_bytes, s.sc));
+    if (c->rmail) HIPC(hipMemsetAsync(c->rmail, 0, sizeof(unsigned long long) * (size_t)(c->rplan.ntx * c->rplan.nty) * 2 * 8 * (size_t)(c->rplan.tx + c->rplan.ty), s.sc));
+    c->rtag = 1;
+  }
+  // per-step tile sums (shared with the LDS-resident engine: sized for the larger tile count)
+  const int rtiles = std::max(ntiles, c->rplan.ntx * c->rplan.nty);
+  if (c->rpartials_cap < nsteps || c->rpartials_tiles < rtiles) {
+    long cap = std::max(1024L, c->rpartials_cap);
+    while (cap < nsteps) cap *= 2;
+    if (c->rpartials) HIPC(hipFree(c->rpartials));
+    c->rpartials = nullptr; c->rpartials_cap = 0;
+    HIPC(hipMalloc((void**)&c->rpartials, sizeof(float) * (size_t)cap * rtiles));
+    c->rpartials_cap = cap; c->rpartials_tiles = rtiles;
+  }
+  int rc = ensure_sums(s, nsteps);
+  if (rc) return rc;
+  lbm::RegTileArgs a;
+  a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
+  a.plane = s.plane; a.pitch = s.pitch; a.nx = c->p.nx; a.ny = c->p.ny;
+  a.blocked = s.blocked; a.omega = c->p.omega;
+  a.accel_row = c->p.ny - 2;
+  a.a1 = c->p.density * c->p.accel / 9.f; a.a2 = c->p.density * c->p.accel / 36.f;
+  a.ty = t.ty; a.ntx = t.ntx; a.nty = t.nty;
+  a.nsteps = nsteps; a.tag0 = c->rtag;
+  a.mail = c->tmail; a.partials = c->rpartials; a.abort_word = c->rabort;
+  c->rtag += (uint32_t)nsteps;
+  const auto wall0 = std::chrono::steady_clock::now();
+  HIPC(hipEventRecord(s.ev_t0, s.sc));
+  const bool fast = (c->variant & lbm::kFastMath) != 0;
+  const dim3 grid(ntiles), block(64 * t.nw);
+  const char* dbg = getenv("LBM_RESIDENT_DEBUG");   // timing experiments (wrong results): see lbm_regtile.hip.h
+  const int dv = dbg ? atoi(dbg) : 0;
+  if (dv >= 1 && dv <= 3 && t.r == 4) {
+    if (dv == 1) hipLaunchKernelGGL((lbm::lbm_regtile<4, 1 | lbm::kResDebugNoWait>), grid, block, 0, s.sc, a);
+    if (dv == 2) hipLaunchKernelGGL((lbm::lbm_regtile<4, 1 | lbm::kResDebugNoWait | lbm::kResDebugNoSend>), grid, block, 0, s.sc, a);
+    if (dv == 3) hipLaunchKernelGGL((lbm::lbm_regtile<4, 1 | lbm::kResDebugNoWait | lbm::kResDebugNoSend | 256>), grid, block, 0, s.sc, a);
+  } else
+  switch (t.r) {
+    case 4: if (fast) hipLaunchKernelGGL((lbm::lbm_regtile<4, 1>), grid, block, 0, s.sc, a); else hipLaunchKernelGGL((lbm::lbm_regtile<4, 0>), grid, block, 0, s.sc, a); break;
+    case 2: if (fast) hipLaunchKernelGGL((lbm::lbm_regtile<2, 1>), grid, block, 0, s.sc, a); else hipLaunchKernelGGL((lbm::lbm_regtile<2, 0>), grid, block, 0, s.sc, a); break;
+    default: if (fast) hipLaunchKernelGGL((lbm::lbm_regtile<1, 1>), grid, block, 0, s.sc, a); else hipLaunchKernelGGL((lbm::lbm_regtile<1, 0>), grid, block, 0, s.sc, a); break;
+  }
+  HIPC(hipGetLastError());
+  hipLaunchKernelGGL(lbm::lbm_fold_steps, dim3(cdiv(nsteps, lbm::kBlock / 64)), dim3(lbm::kBlock), 0, s.sc,
+                     c->rpartials, ntiles, nsteps, s.sums);
+  HIPC(hipGetLastError());
+  HIPC(hipEventRecord(s.ev_t1, s.sc));
+  s.err_host[1] = 0;
+  rc = collect_sums(c, nsteps, av_vels, wall0);
+  if (rc) return rc;
+  if (s.err_host[1] != 0) {
+    c->resident_broken = true;
+    HIPC(hipMemsetAsync(c->rabort, 0, 64, s.sc));
+    HIPC(hipStreamSynchronize(s.sc));
+    if (getenv("LBM_VERBOSE")) fprintf(stderr, "lbm: the register-tile kernel gave up (a tile was not scheduled); using the streaming kernels\n");
     return LBM_OK;
   }
   c->cur ^= 1;
@@ -1548,7 +1661,13 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
     if (rr) return rr;
     if (done) { c->engine_last = 2; return LBM_OK; }
   }
-  if (c->engine == 2) return fail(LBM_EINVAL, c->rplan.tx > 0 ? "the resident kernel gave up on this device" : "this lattice has no resident tiling (engine = 2)");
+  if (c->exchange == 0 && c->slabs.size() == 1 && (c->engine == 3 || c->engine == 0) && c->tplan.ty > 0 && !c->resident_broken) {
+    bool done = false;
+    int rr = run_regtile(c, nsteps, av_vels, &done);
+    if (rr) return rr;
+    if (done) { c->engine_last = 3; return LBM_OK; }
+  }
+  if (c->engine >= 2) return fail(LBM_EINVAL, "the resident kernel gave up on this device, or this lattice has no resident tiling (engine = %d)", c->engine);
   c->engine_last = 1;
   const bool ex = c->exchange != 0;
   const bool pairs = t2_eligible(c) && nsteps >= 2;
@@ -1796,11 +1915,20 @@ extern "C" int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     return LBM_OK;
   }
   if (!strcmp(key, "engine")) {
-    if (value < 0 || value > 2) return fail(LBM_EINVAL, "engine must be 0 (auto), 1 (streaming kernels) or 2 (resident kernel)");
-    if (value == 2 && (c->exchange != 0 || c->slabs.size() != 1 || c->rplan.tx == 0))
-      return fail(LBM_EINVAL, "the resident kernel needs a lattice alone on its GPU that tiles onto the CUs");
+    if (value < 0 || value > 3) return fail(LBM_EINVAL, "engine must be 0 (auto), 1 (streaming kernels), 2 (resident in LDS) or 3 (resident in registers)");
+    if ((value == 2 && (c->exchange != 0 || c->slabs.size() != 1 || c->rplan.tx == 0)) ||
+        (value == 3 && (c->exchange != 0 || c->slabs.size() != 1 || c->tplan.ty == 0)))
+      return fail(LBM_EINVAL, "the resident kernels need a lattice alone on its GPU that tiles onto the CUs");
     c->engine = (int)value;
-    if (value == 2) c->resident_broken = false;
+    if (value >= 2) c->resident_broken = false;
+    return LBM_OK;
+  }
+  if (!strcmp(key, "regtile")) {   // rows per tile * 10 + rows per wave
+    const int ty = (int)(value / 10), r = (int)(value % 10);
+    if (c->exchange != 0 || c->slabs.size() != 1 || !regtile_ok(c, ty, r))
+      return fail(LBM_EINVAL, "register tile of %d rows, %d per wave, does not fit this lattice / device", ty, r);
+    if (c->tmail) { (void)hipFree(c->tmail); c->tmail = nullptr; }
+    regtile_set(c, ty, r);
     return LBM_OK;
   }
   if (!strcmp(key, "resident_tile")) {   // tx * 100000 + ty * 10 + cells per thread
@@ -1834,11 +1962,13 @@ extern "C" int lbm_get_info(const lbm_ctx* c, const char* key, double* value) {
   if (!strcmp(key, "engine")) { *value = c->engine; return LBM_OK; }
   if (!strcmp(key, "engine_last")) { *value = c->engine_last; return LBM_OK; }
   if (!strcmp(key, "engine_next")) {   // what the next lbm_run will try first
-    *value = (c->exchange == 0 && c->slabs.size() == 1 && c->engine == 2 && c->rplan.tx > 0 && !c->resident_broken) ? 2 : 1;
+    *value = (c->exchange == 0 && c->slabs.size() == 1 && !c->resident_broken)
+                 ? ((c->engine == 2 && c->rplan.tx > 0) ? 2 : ((c->engine == 3 || c->engine == 0) && c->tplan.ty > 0) ? 3 : 1) : 1;
     return LBM_OK;
   }
   if (!strcmp(key, "resident_tile")) { *value = c->rplan.tx * 100000.0 + c->rplan.ty * 10.0 + c->rplan.v; return LBM_OK; }
   if (!strcmp(key, "compute_units")) { *value = c->ncu; return LBM_OK; }
+  if (!strcmp(key, "regtile")) { *value = c->tplan.ty * 10.0 + c->tplan.r; return LBM_OK; }
   if (!strcmp(key, "exchange")) { *value = c->exchange; return LBM_OK; }
   if (!strcmp(key, "pitch")) { *value = c->slabs[0].pitch; return LBM_OK; }
   if (!strcmp(key, "hbm_bytes")) {

@@ -177,9 +177,14 @@ def kernel_of(lat, tb):
       lbm_sweep2   two steps per pass, 64x16 tiles + ring  (36 x 66x18/(64x16) + 36) / 2 = 38.9
       lbm_march    four steps per pass, 224 of 256 columns (36 x 258/224 + 36) / 4       = 19.4
       lbm_wave<K>  K steps per pass, 64-2K of 64 columns   (36 x 64/(64-2K) + 36) / K    = 19.3 / 13.7 / 10.5 (K = 4 / 6 / 8)
-      lbm_resident whole run in LDS: one load and one store of the lattice per RUN (reported per step)"""
+      lbm_regtile / lbm_resident  the whole run on chip (registers / LDS): one load and one store of the lattice per
+                   RUN; the figure reported is that, per step -- the kernel is bound by arithmetic and by the hand-off
+                   between neighbouring tiles, not by HBM, so its `frac` is small by design and `equiv_72B_*` is the
+                   number that compares it with the streaming kernels"""
     if int(lat.info("engine_last")) == 2:
         return "lbm_resident", None
+    if int(lat.info("engine_last")) == 3:
+        return "lbm_regtile", None
     if tb >= 4 and int(lat.info("march_kernel")) == 1:       # one wave per 64 columns, 64 - 2K delivered
         return f"lbm_wave<{tb}>", (36.0 * 64 / (64 - 2 * tb) + 36.0) / tb
     if tb == 4:
@@ -241,6 +246,8 @@ def measure(name, world, rank, local_rank, steps, warmup):
     cells = p.nx * p.ny
     local_cells = p.nx * (r1 - r0)
     launches = steps // tb + (steps % tb) // 2 + (steps % tb) % 2 if tb >= 4 else steps // tb + steps % tb
+    if kernel in ("lbm_regtile", "lbm_resident"):
+        launches, tb = 1, steps                              # the whole run is one launch
     launch_s = gpu_ms * 1e-3 / launches                  # mean duration of one launch on this GPU
     lups_per_launch = local_cells * steps / launches
     if min_bytes is None:                                # resident: the lattice crosses HBM twice per run

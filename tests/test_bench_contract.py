@@ -32,7 +32,7 @@ def test_bench_line_single_gpu(gpu):
     assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0
     assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
     assert 0.0 < ro["frac"] <= 1.0                         # priced at the kernel's own minimum bytes: a real fraction
-    assert ro["kernel"].startswith("lbm_sweep2") and abs(ro["min_bytes_per_lattice_update"] - 38.88) < 0.01
+    assert ro["kernel"] == "lbm_regtile" and ro["steps_per_launch"] == 400        # the whole run in one launch, lattice in registers
     assert ro["equiv_72B_frac"] > ro["frac"] and abs(ro["equiv_72B_gbs"] / ro["achieved"] - 72.0 / ro["min_bytes_per_lattice_update"]) < 1e-2
     assert ro["traffic"] is None or ro["traffic"] > 0
     big = d["also"]["8192x8192"]["roofline"]

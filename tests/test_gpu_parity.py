@@ -936,3 +936,43 @@ def test_cli_on_generated_deck(gpu, tmp_path):
     with L.Lattice(p, ob) as lat:
         av = lat.run(40)
     assert np.allclose(av_cli, av, rtol=1e-6, atol=0)       # (%.12E text of a float32)
+
+
+@pytest.mark.parametrize("tile,nx,ny,steps", [
+    ((4, 4), 64, 4, [1]), ((4, 4), 64, 8, [5]), ((8, 4), 64, 8, [5, 2]),      # one tile column: a tile is its own east and west neighbour
+    ((4, 2), 128, 16, [7]), ((16, 1), 128, 16, [7]), ((32, 4), 192, 96, [10]), ((8, 4), 256, 256, [9]),
+    (None, 128, 128, [11, 2]), (None, 128, 256, [12]), (None, 256, 256, [12]), (None, 1024, 1024, [21]),
+    ((32, 4), 1024, 1024, [9]),                                               # two blocks per CU
+])
+def test_register_tile_kernel_equals_single_step_kernel(gpu, tile, nx, ny, steps):
+    """lbm_regtile (engine 3, and the default wherever the lattice tiles onto the CUs: the whole run in one launch,
+    lattice in registers, E/W by DPP lane shifts, tile edges as tagged 8-byte granules through L2) against the
+    one-step streaming kernel: bit-identical lattice, av_vels within summation order."""
+    L = gpu
+    p, ob, cells = _random_case(L, nx, ny, 5)
+    with L.Lattice(p, ob, cells) as a:
+        a.set_option("time_block", 1)
+        av_a = np.concatenate([a.run(n) for n in steps])
+        assert a.info("engine_last") == 1
+        st_a = a.read_state()
+    with L.Lattice(p, ob, cells) as b:
+        if tile is not None:
+            b.set_option("regtile", tile[0] * 10 + tile[1])
+            b.set_option("engine", 3)
+        av_b = np.concatenate([b.run(n) for n in steps])
+        assert b.info("engine_last") == 3                  # (tile None: the default engine picked it)
+        st_b = b.read_state()
+    assert np.array_equal(st_a.view(np.uint32), st_b.view(np.uint32))
+    assert np.allclose(av_a, av_b, rtol=2e-6, atol=0)
+
+
+def test_default_engine_by_lattice(gpu):
+    """The four shipped decks run lbm_regtile by default; lattices that do not tile onto the CUs (width no multiple of
+    64, or too many cells for the register files) run the streaming kernels."""
+    L = gpu
+    for n, want in ((128, 3), (256, 3), (1024, 3), (2048, 1), (100, 1)):
+        p = L.Param(n, n, 10, 10, 0.1, 0.01, 1.85)
+        with L.Lattice(p, np.zeros((n, n), dtype=np.int32)) as lat:
+            assert lat.info("engine_next") == want, n
+            lat.run(3)
+            assert lat.info("engine_last") == want, n
