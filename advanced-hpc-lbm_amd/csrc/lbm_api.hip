@@ -147,6 +147,7 @@ struct Slab {
   hipStream_t sc = nullptr, se = nullptr, sx = nullptr;
   hipEvent_t ev_bnd[2] = {nullptr, nullptr}, ev_recv[2] = {nullptr, nullptr}, ev_int[2] = {nullptr, nullptr};
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+  hipEvent_t ev_march[2] = {nullptr, nullptr};   // "marching launch n of this slab has finished" (by launch parity)
   int accel_row = -1;          // local index of global row ny-2, or -1
   rccl::comm_t comm = nullptr;
   // peer-to-peer halos (LBM_EXCHANGE_P2P): one uncached block holds ghost_s[2], ghost_n[2] and the
@@ -186,6 +187,7 @@ struct lbm_ctx {
   bool p2p_connected = false;
   bool no_comm = false;        // rank mode without RCCL: results are this rank's contribution
   bool p2p_failed = false;     // a peer-to-peer halo wait timed out: the lattice is no longer defined
+  int march_slabs = -1;        // slabs of one process march too (neighbour rows read in place): -1 not decided, 0 no, 1 yes
   // engine: which kernel family lbm_run uses for a lattice alone on its GPU
   //   0 auto = the register-resident kernel (lbm_regtile) where the lattice tiles onto the CUs (the four
   //   shipped decks: 1.5-2x the streaming kernels), the streaming kernels elsewhere,
@@ -317,6 +319,7 @@ int slab_alloc(lbm_ctx* c, Slab& s, bool exchanging) {
   }
   HIPC(hipEventCreate(&s.ev_t0));
   HIPC(hipEventCreate(&s.ev_t1));
+  for (int i = 0; i < 2; ++i) HIPC(hipEventCreateWithFlags(&s.ev_march[i], hipEventDisableTiming));
   return LBM_OK;
 }
 
@@ -520,6 +523,7 @@ void slab_free(Slab& s) {
   if (s.sums_host) (void)hipHostFree(s.sums_host);
   if (s.err_host) (void)hipHostFree(s.err_host);
   if (s.scratch_d) (void)hipFree(s.scratch_d);
+  for (int i = 0; i < 2; ++i) if (s.ev_march[i]) (void)hipEventDestroy(s.ev_march[i]);
   if (s.ev_t0) (void)hipEventDestroy(s.ev_t0);
   if (s.ev_t1) (void)hipEventDestroy(s.ev_t1);
   if (s.comm) (void)rccl::CommDestroy(s.comm);
@@ -640,6 +644,8 @@ int ensure_sums(Slab& s, int nsteps) {
 
 bool plan_resident(lbm_ctx* c);   // resident engines, below
 bool plan_regtile(lbm_ctx* c);
+bool march_slabs_setup(lbm_ctx* c);   // marching kernel across slabs, below
+int march_rows_for(const lbm_ctx* c, int ny_rows);
 
 int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
   const bool exchanging = c->exchange != 0;
@@ -665,6 +671,18 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
     // lbm_sweep2 from 2048^2 up (194 / 226 / 238 GLUPS at 2048^2 / 4096^2 / 8192^2 against 129 / 146 /
     // 150), 0.8x at 1024^2, where 5 strips x 32-row chunks leave the CUs 49 % busy by the estimate
     // below (2048^2: 88 %).
+    if (!getenv("LBM_TIME_BLOCK") && c->time_block == 2 && exchanging) {
+      // slabs of one process: lbm_march with the neighbours' rows read in place, where every slab fills the chip
+      c->time_block = 4;
+      bool ok = c->march_kernel != 1 && march_slabs_setup(c);
+      for (auto& s : c->slabs) {
+        if (!ok) break;
+        const int h = march_rows_for(c, s.nyl), ns = cdiv(c->p.nx, lbm::MarchCfg<kMarchK>::WOUT);
+        const long blocks = (long)ns * cdiv(s.nyl, h), rounds = (blocks + c->ncu - 1) / std::max(c->ncu, 1);
+        if ((double)s.nyl * ns / ((double)rounds * std::max(c->ncu, 1) * (h + 3 * (kMarchK - 1))) < 0.65) ok = false;
+      }
+      if (!ok) { c->time_block = 2; c->march_slabs = -1; }
+    } else
     if (!getenv("LBM_TIME_BLOCK") && c->time_block == 2) {
       c->time_block = 4;
       if (!march_eligible(c)) c->time_block = 2;
@@ -1144,6 +1162,94 @@ int launch_march(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev) {
     default: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 3>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
   }
   HIPC(hipGetLastError());
+  c->cur ^= 1;
+  return LBM_OK;
+}
+
+// ---- lbm_march across the slabs of ONE process.  A slab's K ghost rows on either side are not copied anywhere: the
+// kernel reads them out of the neighbouring slab's lattice (same device, or a peer device over xGMI once peer
+// access is on).  Launch n+1 of a slab waits for launch n of both neighbours: that orders the rows it reads and
+// the rows of its own source lattice (next launch's destination) the neighbours were reading.
+bool march_slabs_setup(lbm_ctx* c) {
+  if (c->march_slabs >= 0) return c->march_slabs == 1;
+  c->march_slabs = 0;
+  if (c->rank_mode || c->exchange == 0 || c->exchange == LBM_EXCHANGE_RCCL) return false;
+  if (c->p.nx % 4 != 0 || c->p.nx < lbm::MarchCfg<kMarchK>::W) return false;
+  const int ns = (int)c->slabs.size();
+  for (auto& s : c->slabs)
+    if (s.nyl < 4 * kMarchK || (double)s.nyl * s.pitch * 4.0 >= 4.0e9) return false;
+  for (int i = 0; i < ns; ++i)
+    for (int d : {(i + ns - 1) % ns, (i + 1) % ns}) {
+      const int a = c->slabs[i].dev, b = c->slabs[d].dev;
+      if (a == b) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) { (void)hipGetLastError(); return false; }
+      if (hipSetDevice(a) != hipSuccess) return false;
+      const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+      (void)hipGetLastError();
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return false;
+    }
+  c->march_slabs = 1;
+  return true;
+}
+inline bool march_slabs_on(lbm_ctx* c) { return c->time_block == kMarchK && c->march_kernel != 1 && march_slabs_setup(c); }
+
+int march_rows_for(const lbm_ctx* c, int ny_rows) {
+  const int ns = cdiv(c->p.nx, lbm::MarchCfg<kMarchK>::WOUT), ncu = std::max(c->ncu, 1);
+  int best_h = std::min(ny_rows, 256);
+  double best = -1.0;
+  for (int h = std::min(ny_rows, 32); h <= std::min(ny_rows, 1024); ++h) {
+    const long blocks = (long)ns * cdiv(ny_rows, h);
+    const long rounds = (blocks + ncu - 1) / ncu;
+    const double eff = (double)ny_rows * ns / ((double)rounds * ncu * (h + 3 * (kMarchK - 1)));
+    if (eff > best + 1e-9) { best = eff; best_h = h; }
+  }
+  return best_h;
+}
+inline int march_slab_blocks(const lbm_ctx* c, const Slab& s) {
+  return cdiv(c->p.nx, lbm::MarchCfg<kMarchK>::WOUT) * cdiv(s.nyl, march_rows_for(c, s.nyl));
+}
+
+// One marching launch group over all slabs: steps tt .. tt+K-1, launch index li.
+int launch_march_slabs(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev) {
+  using Cfg = lbm::MarchCfg<kMarchK>;
+  const int ns = (int)c->slabs.size(), q = li & 1, qp = q ^ 1;
+  for (int i = 0; i < ns; ++i) {
+    Slab& s = c->slabs[i];
+    Slab& so = c->slabs[(i + ns - 1) % ns];
+    Slab& no = c->slabs[(i + 1) % ns];
+    HIPC(hipSetDevice(s.dev));
+    HIPC(hipStreamWaitEvent(s.sc, so.ev_march[qp], 0));
+    HIPC(hipStreamWaitEvent(s.sc, no.ev_march[qp], 0));
+    lbm::MarchArgs a;
+    a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
+    a.plane = s.plane; a.pitch = s.pitch; a.nx = c->p.nx; a.ny = s.nyl;
+    a.blocked = s.blocked; a.omega = c->p.omega;
+    a.accel_row = lbm::kNoRow; a.accel_out = accel_out ? 1 : 0;
+    a.a1 = c->p.density * c->p.accel / 9.f; a.a2 = c->p.density * c->p.accel / 36.f;
+    a.H = march_rows_for(c, s.nyl);
+    a.nstrips = cdiv(c->p.nx, Cfg::WOUT); a.nchunks = cdiv(s.nyl, a.H);
+    const int nb = a.nstrips * a.nchunks;
+    if ((long)kMarchK * nb > s.partial_cap) return fail(LBM_EINVAL, "marching kernel: %d blocks exceed the partial-sum buffer", nb);
+    a.partials = s.partials[q];
+    a.prev = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
+    if (fold_prev) { a.prev = s.partials[qp]; a.prev_count = nb; a.prev_sum = s.sums + (tt - kMarchK); }
+    a.src_s = so.lat[c->cur]; a.src_n = no.lat[c->cur];
+    a.plane_s = so.plane; a.plane_n = no.plane; a.ny_s = so.nyl; a.ny_n = no.nyl;
+    a.blocked_s = so.blocked; a.blocked_n = no.blocked;
+    // the lattice's accelerate row (ny-2) in this slab's row numbers, and its periodic images: one of them may fall
+    // into the K rows this slab recomputes on a neighbour's behalf
+    const int ar = (c->p.ny - 2) - s.row0;
+    a.acc_rows[0] = ar; a.acc_rows[1] = ar - c->p.ny; a.acc_rows[2] = ar + c->p.ny;
+    switch ((int)(c->variant & (lbm::kFastMath | lbm::kNtStore))) {
+      case 0: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 0, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
+      case 1: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 1, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
+      case 2: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 2, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
+      default: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 3, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
+    }
+    HIPC(hipGetLastError());
+    HIPC(hipEventRecord(s.ev_march[q], s.sc));
+  }
   c->cur ^= 1;
   return LBM_OK;
 }
@@ -1676,7 +1782,8 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
   for (auto& s : c->slabs)
     if ((rc = ensure_sums(s, nsteps))) return rc;
 
-  // ---- prologue: accelerate phase of the first step; first halo exchange (parity 1 = "launch -1")
+  // ---- prologue: accelerate phase of the first step
+  const bool slabs_march = ex && march_slabs_on(c) && nsteps >= kMarchK;
   for (auto& s : c->slabs) {
     HIPC(hipSetDevice(s.dev));
     if (s.accel_row >= 0) {
@@ -1684,19 +1791,26 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
                          s.lat[c->cur], s.plane, s.pitch, nx, s.accel_row, s.blocked, a1, a2);
       HIPC(hipGetLastError());
     }
-    if (ex) {
+    if (slabs_march) HIPC(hipEventRecord(s.ev_march[1], s.sc));   // "launch -1": the starting lattice is in place
+  }
+  // halo buffers of the launches that trade halos (lbm_sweep2 / lbm_sweep on slabs), filled from the current lattice
+  // as "launch par" (the launch before the first one that reads them)
+  auto prime_halos = [&](int par) -> int {
+    for (auto& s : c->slabs) {
+      HIPC(hipSetDevice(s.dev));
       if (s.nyl >= 2)
         hipLaunchKernelGGL(lbm::lbm_pack_halos9, dim3(cdiv(nx, 256)), dim3(256), 0, s.sc,
-                           s.lat[c->cur], s.plane, s.pitch, nx, s.nyl, s.send_s[1], s.send_n[1]);
+                           s.lat[c->cur], s.plane, s.pitch, nx, s.nyl, s.send_s[par], s.send_n[par]);
       else
         hipLaunchKernelGGL(lbm::lbm_pack_halos, dim3(cdiv(nx, 256)), dim3(256), 0, s.sc,
-                           s.lat[c->cur], s.plane, s.pitch, nx, s.nyl, s.send_s[1] + 3L * nx, s.send_n[1] + 3L * nx);
+                           s.lat[c->cur], s.plane, s.pitch, nx, s.nyl, s.send_s[par] + 3L * nx, s.send_n[par] + 3L * nx);
       HIPC(hipGetLastError());
-      HIPC(hipEventRecord(s.ev_bnd[1], s.sc));   // "edge rows of launch -1 are in place"
-      if (split_edge_stream(c, s)) HIPC(hipEventRecord(s.ev_int[1], s.sc));   // "interior of launch -1 is done"
+      HIPC(hipEventRecord(s.ev_bnd[par], s.sc));   // "edge rows of launch -1 are in place"
+      if (split_edge_stream(c, s)) HIPC(hipEventRecord(s.ev_int[par], s.sc));   // "interior of launch -1 is done"
     }
-  }
-  if (ex && (rc = pairs ? exchange_halos(c, 1, 0, lbm::kHaloSlots) : exchange_halos(c, 1, 3, 3))) return rc;
+    return pairs ? exchange_halos(c, par, 0, lbm::kHaloSlots) : exchange_halos(c, par, 3, 3);
+  };
+  if (ex && !slabs_march && (rc = prime_halos(1))) return rc;
 
   const auto wall0 = std::chrono::steady_clock::now();
   for (auto& s : c->slabs) {
@@ -1708,6 +1822,26 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
   // Launch index li numbers the launch groups (a pair of steps or a single step); its parity
   // selects the halo / partial-sum buffers.
   int li = 0, tt = 0;
+  if (slabs_march) {                                   // groups of K steps, row-marching, every slab of this process
+    const int ngroups = nsteps / kMarchK;
+    for (int g = 0; g < ngroups; ++g, ++li, tt += kMarchK)
+      if ((rc = launch_march_slabs(c, li, tt, tt + kMarchK < nsteps, g > 0))) return rc;
+    for (auto& s : c->slabs) {
+      HIPC(hipSetDevice(s.dev));
+      const int nb = march_slab_blocks(c, s);
+      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(kMarchK), dim3(lbm::kBlock), 0, s.sc, s.partials[(li - 1) & 1], nb,
+                         s.sums + (tt - kMarchK), nb);
+      HIPC(hipGetLastError());
+    }
+    if (tt < nsteps) {
+      // the remaining steps trade halos: every slab's marching launches must be over before a neighbour packs / copies
+      for (auto& s : c->slabs) {
+        HIPC(hipSetDevice(s.dev));
+        for (auto& o : c->slabs) HIPC(hipStreamWaitEvent(s.sc, o.ev_march[(li - 1) & 1], 0));
+      }
+      if ((rc = prime_halos((li & 1) ^ 1))) return rc;
+    }
+  } else
   if (march_eligible(c) && nsteps >= c->time_block) {   // groups of K steps, row-marching (lone slab)
     const int K = c->time_block, ngroups = nsteps / K;
     const bool wave = use_wave_kernel(c);
@@ -1953,7 +2087,10 @@ extern "C" int lbm_get_info(const lbm_ctx* c, const char* key, double* value) {
   if (!strcmp(key, "kernel_variant")) { *value = (double)c->variant; return LBM_OK; }
   if (!strcmp(key, "time_block")) { *value = c->time_block; return LBM_OK; }
   if (!strcmp(key, "t2_threads")) { *value = c->t2_threads; return LBM_OK; }
-  if (!strcmp(key, "time_block_active")) { *value = march_eligible(c) ? c->time_block : t2_eligible(c) ? 2 : 1; return LBM_OK; }
+  if (!strcmp(key, "time_block_active")) {
+    *value = (march_eligible(c) || (c->exchange != 0 && march_slabs_on(const_cast<lbm_ctx*>(c)))) ? c->time_block : t2_eligible(c) ? 2 : 1;
+    return LBM_OK;
+  }
   if (!strcmp(key, "march_kernel")) { *value = (march_eligible(c) && use_wave_kernel(c)) ? 1 : 0; return LBM_OK; }
   if (!strcmp(key, "wave_rows")) { *value = c->wave_rows; return LBM_OK; }
   if (!strcmp(key, "wave_capacity")) { *value = c->wave_capacity; return LBM_OK; }

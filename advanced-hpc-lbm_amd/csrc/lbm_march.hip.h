@@ -49,6 +49,17 @@ struct MarchArgs {
   const float* prev;           // the previous launch's partials, folded by block 0 (or nullptr)
   int prev_count;              // its block count
   double* prev_sum;            // K doubles
+  // ---- a slab with neighbours (SLAB kernels): `ny` rows are this slab's; the K rows below row 0 and above row
+  // ny-1 are READ STRAIGHT FROM THE NEIGHBOURS' LATTICES (same process: peer access; other process: hipIpc mapping;
+  // over xGMI when the neighbour is another GPU) -- no halo buffers, no packing, no copies.  The host orders the
+  // launches: launch n+1 of a slab starts after launch n of both neighbours has finished (that covers the rows it
+  // reads and the rows of ITS source lattice the neighbours were still reading).
+  const float* src_s; const float* src_n;            // the neighbours' lattices at step t
+  long plane_s, plane_n;                              // their plane strides
+  int ny_s, ny_n;                                     // their row counts (row -1 here = row ny_s-1 of the southern one)
+  const uint8_t* blocked_s; const uint8_t* blocked_n;
+  int acc_rows[3];             // this slab's row indices of the lattice's accelerate row and of its periodic images
+                               // (any of them may lie in the K rows outside the slab; kNoRow where there is none)
 };
 
 template <int K>
@@ -92,6 +103,15 @@ __device__ __forceinline__ void march_dma4(unsigned voff, const void* base, unsi
 
 __device__ __forceinline__ int march_wrap(int r, int n) { r %= n; return r < 0 ? r + n : r; }
 
+// A pointer the compiler cannot prove wave-uniform, made so (it IS uniform: it depends on block and iteration only);
+// the LDS-DMA wants its base in scalar registers.
+template <typename T>
+__device__ __forceinline__ const T* march_uniform(const T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const T*)(((unsigned long long)hi << 32) | lo);
+}
+
 // What a block knows about its place in the lattice.
 struct MarchGeom {
   int X0, Y0, wx, hy;          // output columns [X0, X0+wx), rows [Y0, Y0+hy)
@@ -104,7 +124,7 @@ constexpr int kMarchFirst = 0, kMarchMiddle = 1, kMarchLast = 2;
 // The loop of one level.  ROLE: first = level 1 (pulls from the source ring, its four waves also fetch),
 // middle = levels 2..K-1, last = level K (stores to the destination lattice).  One copy of the loop per
 // role keeps each wave's instruction stream free of the other roles' branches and addresses.
-template <int K, int MODE, int ROLE>
+template <int K, int MODE, int ROLE, bool SLAB>
 __device__ __forceinline__ float march_level(const MarchArgs& a, const MarchGeom& g, float* lds, int t, int lane, int lvl, int wave) {
   using C = MarchCfg<K>;
   constexpr bool FAST = (MODE & kFastMath) != 0, NTS = (MODE & kNtStore) != 0;
@@ -128,22 +148,38 @@ __device__ __forceinline__ float march_level(const MarchArgs& a, const MarchGeom
   const unsigned funit = (wave == 3) ? 1u : 4u;                  // bytes per cell of what this wave fetches
   int gxl = g.X0 - C::HALO + 4 * lane;
   gxl += (gxl < 0) ? a.nx : 0; gxl -= (gxl >= a.nx) ? a.nx : 0;
-  int fgy = march_wrap(g.Yb - 1, a.ny);                           // lattice row of the next source row to fetch
-  unsigned fvoff = ((unsigned)fgy * (unsigned)a.pitch + (unsigned)gxl) * funit;
+  // lone lattice: the row counter wraps inside [0, ny); slab: it runs from -K on and rows outside [0, ny) are the neighbours'
+  int fgy = SLAB ? g.Yb - 1 : march_wrap(g.Yb - 1, a.ny);        // row of the next source row to fetch
+  unsigned fvoff = SLAB ? 0u : ((unsigned)fgy * (unsigned)a.pitch + (unsigned)gxl) * funit;
   const unsigned fstep = (unsigned)a.pitch * funit, fback = (unsigned)(a.ny - 1) * (unsigned)a.pitch * funit;
   const unsigned lds0 = (unsigned)(size_t)lds;                    // LDS byte address of the array (low half of the flat address)
   const unsigned fring = lds0 + 4u * (unsigned)((wave == 0) ? C::r0A : (wave == 1) ? C::r0B : C::r0C);
   auto fetch = [&](int slot6, int slot12) {   // the next row in sequence, into ring slot rho % 6 (rho % 12)
+    const float *b0 = fb0, *b1 = fb1, *b2 = fb2;
+    const uint8_t* bm = a.blocked;
+    if (SLAB) {
+      // whose row is it?  (rows fetched beyond the K a level ever pulls -- the prefetch runs on past the chunk -- are clamped)
+      int row = fgy;
+      if (fgy < 0) {
+        row = max(a.ny_s + fgy, 0);
+        b0 = a.src_s + pk0 * a.plane_s; b1 = a.src_s + pk1 * a.plane_s; b2 = a.src_s + pk2 * a.plane_s; bm = a.blocked_s;
+      } else if (fgy >= a.ny) {
+        row = min(fgy - a.ny, a.ny_n - 1);
+        b0 = a.src_n + pk0 * a.plane_n; b1 = a.src_n + pk1 * a.plane_n; b2 = a.src_n + pk2 * a.plane_n; bm = a.blocked_n;
+      }
+      fvoff = ((unsigned)__builtin_amdgcn_readfirstlane(row) * (unsigned)a.pitch + (unsigned)gxl) * funit;
+      b0 = march_uniform(b0); b1 = march_uniform(b1); b2 = march_uniform(b2); bm = march_uniform(bm);
+    }
     if (wave == 3) {
-      march_dma4(fvoff, a.blocked, lds0 + 4u * (unsigned)(C::mask0 + slot12 * 64));
-      march_dma4(fvoff, a.blocked, lds0 + 4u * (unsigned)(C::mask0 + (slot12 + C::SM) * 64));
+      march_dma4(fvoff, bm, lds0 + 4u * (unsigned)(C::mask0 + slot12 * 64));
+      march_dma4(fvoff, bm, lds0 + 4u * (unsigned)(C::mask0 + (slot12 + C::SM) * 64));
     } else {
-      march_dma16(fvoff, fb0, fring + 4u * (unsigned)((0 * S0 + slot6) * W));
-      march_dma16(fvoff, fb1, fring + 4u * (unsigned)((1 * S0 + slot6) * W));
-      march_dma16(fvoff, fb2, fring + 4u * (unsigned)((2 * S0 + slot6) * W));
+      march_dma16(fvoff, b0, fring + 4u * (unsigned)((0 * S0 + slot6) * W));
+      march_dma16(fvoff, b1, fring + 4u * (unsigned)((1 * S0 + slot6) * W));
+      march_dma16(fvoff, b2, fring + 4u * (unsigned)((2 * S0 + slot6) * W));
     }
     ++fgy;
-    if (fgy == a.ny) { fgy = 0; fvoff -= fback; } else { fvoff += fstep; }
+    if (!SLAB) { if (fgy == a.ny) { fgy = 0; fvoff -= fback; } else { fvoff += fstep; } }
   };
   auto fetch_wait = [&]() {   // all but this wave's four newest row fetches have landed
     if (wave == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -161,8 +197,10 @@ __device__ __forceinline__ float march_level(const MarchArgs& a, const MarchGeom
   const int j_own0 = (K - 1) + 2 * lvl, j_own1 = j_own0 + g.hy - 1;  // ... whose row belongs to this chunk (speed sum)
   // iterations in which this level's row is the accelerate row (the chunk plus its fill rows may pass it twice)
   const bool do_acc = (ROLE != kMarchLast) || (a.accel_out != 0);
-  const int j_acc = do_acc ? march_wrap(a.accel_row - g.Yb, a.ny) + 2 * lvl : -1;
-  const int j_acc2 = do_acc ? j_acc + a.ny : -1;
+  // (row r is computed in iteration r - Yb + 2 lvl)
+  const int j_acc = !do_acc ? -1 : SLAB ? a.acc_rows[0] - g.Yb + 2 * lvl : march_wrap(a.accel_row - g.Yb, a.ny) + 2 * lvl;
+  const int j_acc2 = !do_acc ? -1 : SLAB ? a.acc_rows[1] - g.Yb + 2 * lvl : j_acc + a.ny;
+  const int j_acc3 = (do_acc && SLAB) ? a.acc_rows[2] - g.Yb + 2 * lvl : -1;
   const bool col_own = (t >= C::HALO) && (t < C::HALO + g.wx);
   const float* in0 = lds + t;                                           // level 1 pulls from the source ring
   const float* inL = lds + C::lvl0 + (lvl - 1) * C::lvl_floats + t;     // levels 2..K from the ring below
@@ -211,7 +249,7 @@ __device__ __forceinline__ float march_level(const MarchArgs& a, const MarchGeom
       }
       const bool blk = mk[jj * 256] != 0;
       const float sp = collide_cell<FAST>(p, blk, a.omega);
-      if (j == j_acc || j == j_acc2) accelerate_cell(p, blk, a.a1, a.a2);
+      if (j == j_acc || j == j_acc2 || (SLAB && j == j_acc3)) accelerate_cell(p, blk, a.a1, a.a2);
       sum += (col_own && j >= j_own0 && j <= j_own1) ? sp : 0.f;
       if (ROLE != kMarchLast) {
         constexpr int wa = jj % C::SLA, wb = jj % C::SLB, wc = jj % C::SLC;
@@ -266,7 +304,7 @@ __device__ __forceinline__ float march_level(const MarchArgs& a, const MarchGeom
   return sum;
 }
 
-template <int K, int MODE>
+template <int K, int MODE, bool SLAB = false>
 __global__ __launch_bounds__(K * 256) void lbm_march(const MarchArgs a) {
   using C = MarchCfg<K>;
   constexpr int NW = K * 4;
@@ -307,9 +345,9 @@ __global__ __launch_bounds__(K * 256) void lbm_march(const MarchArgs a) {
   g.niter = g.hy + 3 * (K - 1);
 
   float sum;
-  if (lvl == 0) sum = march_level<K, MODE, kMarchFirst>(a, g, lds, t, lane, lvl, wave);
-  else if (lvl == K - 1) sum = march_level<K, MODE, kMarchLast>(a, g, lds, t, lane, lvl, wave);
-  else sum = march_level<K, MODE, kMarchMiddle>(a, g, lds, t, lane, lvl, wave);
+  if (lvl == 0) sum = march_level<K, MODE, kMarchFirst, SLAB>(a, g, lds, t, lane, lvl, wave);
+  else if (lvl == K - 1) sum = march_level<K, MODE, kMarchLast, SLAB>(a, g, lds, t, lane, lvl, wave);
+  else sum = march_level<K, MODE, kMarchMiddle, SLAB>(a, g, lds, t, lane, lvl, wave);
 
   // per level: block sum of the speeds -> partials[level][block]
   sum = wave_sum(sum);
