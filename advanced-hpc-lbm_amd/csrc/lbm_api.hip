@@ -158,6 +158,12 @@ struct Slab {
   char* peer_n = nullptr;
   bool peer_s_ipc = false, peer_n_ipc = false;
   uint32_t* counters = nullptr;  // device: [0] cnt_s, [16] cnt_n, [32] err (separate 64-B lines)
+  // peer-to-peer marching launches read the neighbours' lattices in place: [0] = southern, [1] = northern neighbour
+  const float* nb_lat[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [side][lattice 0 / 1]
+  const uint8_t* nb_blocked[2] = {nullptr, nullptr};
+  long nb_plane[2] = {0, 0};
+  int nb_nyl[2] = {0, 0};
+  void* nb_ipc[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // hipIpc mappings to close (rank mode)
   uint32_t cnt_s_total = 0, cnt_n_total = 0;
 };
 
@@ -238,6 +244,14 @@ void slab_free_halos(Slab& s) {
   if (s.blocked_gs) (void)hipFree(s.blocked_gs);
   if (s.blocked_gn) (void)hipFree(s.blocked_gn);
   s.blocked_gs = s.blocked_gn = nullptr;
+  for (int side = 0; side < 2; ++side)
+    for (int i = 0; i < 3; ++i) {
+      if (s.nb_ipc[side][i] && (side == 0 || s.nb_ipc[1][i] != s.nb_ipc[0][i])) (void)hipIpcCloseMemHandle(s.nb_ipc[side][i]);
+    }
+  for (int side = 0; side < 2; ++side) {
+    for (int i = 0; i < 3; ++i) s.nb_ipc[side][i] = nullptr;
+    s.nb_lat[side][0] = s.nb_lat[side][1] = nullptr; s.nb_blocked[side] = nullptr;
+  }
   if (s.peer_s_ipc && s.peer_s) (void)hipIpcCloseMemHandle(s.peer_s);
   if (s.peer_n_ipc && s.peer_n && s.peer_n != s.peer_s) (void)hipIpcCloseMemHandle(s.peer_n);
   s.peer_s = s.peer_n = nullptr; s.peer_s_ipc = s.peer_n_ipc = false;
@@ -253,7 +267,7 @@ int slab_alloc_halos(lbm_ctx* c, Slab& s) {
     HIPC(hipMalloc((void**)&s.blocked_gs, (size_t)nx));
     HIPC(hipMalloc((void**)&s.blocked_gn, (size_t)nx));
     s.halo_bytes = (sizeof(float) * lbm::kHaloSlots * (size_t)nx + 255) / 256 * 256;
-    const size_t total = 4 * s.halo_bytes + 512;
+    const size_t total = 4 * s.halo_bytes + 512 + 256;   // halos, two flag lines, the hipIpc handles of both lattices and the obstacle map
     // uncached: the neighbours write it over xGMI behind this GPU's L2.  Fine-grained memory is NOT
     // accepted as a substitute (the local L2 may keep ghost rows a neighbour has since rewritten):
     // without uncached memory peer-to-peer halos count as unavailable and the caller uses RCCL.
@@ -266,6 +280,15 @@ int slab_alloc_halos(lbm_ctx* c, Slab& s) {
     for (int i = 0; i < 2; ++i) {
       s.ghost_s[i] = (float*)(s.comm_block + (size_t)i * s.halo_bytes);
       s.ghost_n[i] = (float*)(s.comm_block + (size_t)(2 + i) * s.halo_bytes);
+    }
+    if (c->rank_mode && c->nranks > 1) {
+      // a neighbouring PROCESS reads this slab's rows in place (marching launches): it finds the handles here
+      hipIpcMemHandle_t h[3];
+      HIPC(hipIpcGetMemHandle(&h[0], s.lat[0]));
+      HIPC(hipIpcGetMemHandle(&h[1], s.lat[1]));
+      HIPC(hipIpcGetMemHandle(&h[2], s.blocked));
+      static_assert(sizeof(hipIpcMemHandle_t) == 64, "three handles in 192 bytes");
+      HIPC(hipMemcpy(s.comm_block + 4 * s.halo_bytes + 512, h, sizeof(h), hipMemcpyHostToDevice));
     }
   } else {
     const size_t hb = sizeof(float) * lbm::kHaloSlots * (size_t)nx;
@@ -645,6 +668,7 @@ int ensure_sums(Slab& s, int nsteps) {
 bool plan_resident(lbm_ctx* c);   // resident engines, below
 bool plan_regtile(lbm_ctx* c);
 bool march_slabs_setup(lbm_ctx* c);   // marching kernel across slabs, below
+bool p2p_march_pays(const lbm_ctx* c);
 int march_rows_for(const lbm_ctx* c, int ny_rows);
 
 int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
@@ -671,6 +695,11 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
     // lbm_sweep2 from 2048^2 up (194 / 226 / 238 GLUPS at 2048^2 / 4096^2 / 8192^2 against 129 / 146 /
     // 150), 0.8x at 1024^2, where 5 strips x 32-row chunks leave the CUs 49 % busy by the estimate
     // below (2048^2: 88 %).
+    if (!getenv("LBM_TIME_BLOCK") && c->time_block == 2 && exchanging && c->exchange == LBM_EXCHANGE_P2P) {
+      // peer-to-peer halos (one process or one process per GPU): lbm_march where the smallest slab fills the chip
+      // (a function of the lattice and the number of slabs only: every rank decides alike)
+      if (c->p.nx % 4 == 0 && c->p.nx >= lbm::MarchCfg<kMarchK>::W && c->p.ny / c->nranks >= 4 * kMarchK && p2p_march_pays(c)) c->time_block = 4;
+    } else
     if (!getenv("LBM_TIME_BLOCK") && c->time_block == 2 && exchanging) {
       // slabs of one process: lbm_march with the neighbours' rows read in place, where every slab fills the chip
       c->time_block = 4;
@@ -738,6 +767,11 @@ int p2p_connect_local(lbm_ctx* c) {
     }
     s.peer_s = so.comm_block;
     s.peer_n = no.comm_block;
+    Slab* nb[2] = {&so, &no};
+    for (int side = 0; side < 2; ++side) {
+      s.nb_lat[side][0] = nb[side]->lat[0]; s.nb_lat[side][1] = nb[side]->lat[1];
+      s.nb_blocked[side] = nb[side]->blocked; s.nb_plane[side] = nb[side]->plane; s.nb_nyl[side] = nb[side]->nyl;
+    }
   }
   c->p2p_connected = true;
   return LBM_OK;
@@ -763,6 +797,32 @@ int p2p_connect_ipc(lbm_ctx* c, const char* handles, int nranks) {
   if (rc) return rc;
   if (north == south) { s.peer_n = s.peer_s; s.peer_n_ipc = false; }
   else if ((rc = open(north, &s.peer_n, &s.peer_n_ipc))) return rc;
+  // the neighbours' lattices and obstacle maps, for the marching launches (their handles sit in their halo blocks)
+  const int nbr[2] = {south, north};
+  char* blocks[2] = {s.peer_s, s.peer_n};
+  for (int side = 0; side < 2; ++side) {
+    const int r = nbr[side];
+    const int r0 = (int)((long)r * c->p.ny / nranks), nyl = (int)((long)(r + 1) * c->p.ny / nranks) - r0;
+    s.nb_nyl[side] = nyl;
+    s.nb_plane[side] = (long)nyl * s.pitch + 5184;       // (slab_alloc's rule)
+    if (r == c->rank) {
+      s.nb_lat[side][0] = s.lat[0]; s.nb_lat[side][1] = s.lat[1]; s.nb_blocked[side] = s.blocked;
+    } else if (side == 1 && north == south) {
+      for (int i = 0; i < 3; ++i) s.nb_ipc[1][i] = s.nb_ipc[0][i];
+      s.nb_lat[1][0] = s.nb_lat[0][0]; s.nb_lat[1][1] = s.nb_lat[0][1]; s.nb_blocked[1] = s.nb_blocked[0];
+    } else {
+      hipIpcMemHandle_t h[3];
+      HIPC(hipMemcpy(h, blocks[side] + 4 * s.halo_bytes + 512, sizeof(h), hipMemcpyDeviceToHost));
+      for (int i = 0; i < 3; ++i) {
+        void* ptr = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&ptr, h[i], hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(LBM_EHIP, "hipIpcOpenMemHandle(lattice of rank %d): %s", r, hipGetErrorString(e)); }
+        s.nb_ipc[side][i] = ptr;
+      }
+      s.nb_lat[side][0] = (const float*)s.nb_ipc[side][0]; s.nb_lat[side][1] = (const float*)s.nb_ipc[side][1];
+      s.nb_blocked[side] = (const uint8_t*)s.nb_ipc[side][2];
+    }
+  }
   c->p2p_connected = true;
   return LBM_OK;
 }
@@ -1629,6 +1689,23 @@ lbm::P2PSync p2p_sync(Slab& s, uint32_t seq, int blocks_s, int blocks_n) {
 inline float* p2p_remote_s(const Slab& s, uint32_t seq) { return (float*)(s.peer_s + (size_t)(2 + (seq & 1)) * s.halo_bytes); }  // its ghost_n
 inline float* p2p_remote_n(const Slab& s, uint32_t seq) { return (float*)(s.peer_n + (size_t)(seq & 1) * s.halo_bytes); }        // its ghost_s
 
+// Peer-to-peer contexts march too (lbm_march, neighbours' rows read in place over xGMI) where every slab fills the
+// chip.  The decision uses the lattice, the number of slabs and the options only -- every rank must come to the same
+// answer, the two protocols do not mix.
+bool p2p_march_on(const lbm_ctx* c) {
+  if (c->time_block != kMarchK || c->march_kernel == 1 || c->exchange != LBM_EXCHANGE_P2P) return false;
+  if (c->p.nx % 4 != 0 || c->p.nx < lbm::MarchCfg<kMarchK>::W) return false;
+  const int rows = c->p.ny / c->nranks;                     // the smallest slab
+  if (rows < 4 * kMarchK || (double)(rows + 1) * c->slabs[0].pitch * 4.0 >= 4.0e9) return false;
+  for (auto& s : c->slabs) if (!s.nb_lat[0][0] || !s.nb_lat[1][0]) return false;   // (connect failed: an error everywhere)
+  return true;
+}
+bool p2p_march_pays(const lbm_ctx* c) {                      // same estimate as for a lone lattice, on the smallest slab
+  const int rows = c->p.ny / c->nranks, h = march_rows_for(c, rows), ns = cdiv(c->p.nx, lbm::MarchCfg<kMarchK>::WOUT), ncu = std::max(c->ncu, 1);
+  const long blocks = (long)ns * cdiv(rows, h), rounds = (blocks + ncu - 1) / ncu;
+  return (double)rows * ns / ((double)rounds * ncu * (h + 3 * (kMarchK - 1))) >= 0.65;
+}
+
 // The step loop with peer-to-peer halos: one stream per slab, no events, no host-side exchange.
 // Two-step launches carry the hand-off themselves (edge tiles first); single steps are bracketed
 // by a wait launch and a push launch.
@@ -1652,8 +1729,8 @@ int run_p2p(lbm_ctx* c, int nsteps, float* av_vels) {
     return LBM_OK;
   };
 
-  // ---- prologue: accelerate phase of the first step, then push the halos of the starting lattice
-  uint32_t seq = ++c->seq;
+  // ---- prologue: accelerate phase of the first step
+  uint32_t seq = 0;
   for (auto& s : c->slabs) {
     HIPC(hipSetDevice(s.dev));
     if (s.accel_row >= 0) {
@@ -1661,7 +1738,6 @@ int run_p2p(lbm_ctx* c, int nsteps, float* av_vels) {
                          s.lat[c->cur], s.plane, s.pitch, nx, s.accel_row, s.blocked, a1, a2);
       HIPC(hipGetLastError());
     }
-    if ((rc = push(s, s.lat[c->cur], seq, true))) return rc;
   }
   const auto wall0 = std::chrono::steady_clock::now();
   for (auto& s : c->slabs) {
@@ -1670,8 +1746,77 @@ int run_p2p(lbm_ctx* c, int nsteps, float* av_vels) {
   }
 
   int li = 0, tt = 0;
-  if (pairs) {
-    const int npairs = nsteps / 2;
+  // ---- groups of K steps with lbm_march: the K ghost rows either side are read straight out of the neighbours'
+  // lattices.  Launch group seq of a slab starts once both neighbours have raised seq-1 ("my launch seq-1 is over":
+  // their rows are final, and they no longer read the lattice this launch overwrites) and raises seq when it is over.
+  if (p2p_march_on(c) && nsteps >= kMarchK) {
+    using Cfg = lbm::MarchCfg<kMarchK>;
+    auto raise = [&](Slab& s, uint32_t q) -> int {
+      const size_t f = 4 * s.halo_bytes;
+      hipLaunchKernelGGL(lbm::lbm_p2p_raise, dim3(1), dim3(64), 0, s.sc, (uint32_t*)(s.peer_s + f + 256), (uint32_t*)(s.peer_n + f), q);
+      HIPC(hipGetLastError());
+      return LBM_OK;
+    };
+    seq = ++c->seq;                                     // "the starting lattice is in place"
+    for (auto& s : c->slabs) {
+      HIPC(hipSetDevice(s.dev));
+      if ((rc = push(s, nullptr, seq, false))) return rc;   // (the neighbours are through with the previous run)
+      if ((rc = raise(s, seq))) return rc;
+    }
+    const int ngroups = nsteps / kMarchK;
+    for (int g = 0; g < ngroups; ++g, ++li, tt += kMarchK) {
+      seq = ++c->seq;
+      const int q = li & 1, qp = q ^ 1;
+      for (auto& s : c->slabs) {
+        HIPC(hipSetDevice(s.dev));
+        if ((rc = push(s, nullptr, seq, false))) return rc;   // wait for both neighbours' seq-1
+        lbm::MarchArgs a;
+        a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
+        a.plane = s.plane; a.pitch = s.pitch; a.nx = nx; a.ny = s.nyl;
+        a.blocked = s.blocked; a.omega = c->p.omega;
+        a.accel_row = lbm::kNoRow; a.accel_out = (tt + kMarchK < nsteps) ? 1 : 0;
+        a.a1 = a1; a.a2 = a2;
+        a.H = march_rows_for(c, s.nyl);
+        a.nstrips = cdiv(nx, Cfg::WOUT); a.nchunks = cdiv(s.nyl, a.H);
+        const int nb = a.nstrips * a.nchunks;
+        if ((long)kMarchK * nb > s.partial_cap) return fail(LBM_EINVAL, "marching kernel: %d blocks exceed the partial-sum buffer", nb);
+        a.partials = s.partials[q];
+        a.prev = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
+        if (g > 0) { a.prev = s.partials[qp]; a.prev_count = nb; a.prev_sum = s.sums + (tt - kMarchK); }
+        a.src_s = s.nb_lat[0][c->cur]; a.src_n = s.nb_lat[1][c->cur];
+        a.plane_s = s.nb_plane[0]; a.plane_n = s.nb_plane[1]; a.ny_s = s.nb_nyl[0]; a.ny_n = s.nb_nyl[1];
+        a.blocked_s = s.nb_blocked[0]; a.blocked_n = s.nb_blocked[1];
+        const int ar = (c->p.ny - 2) - s.row0;
+        a.acc_rows[0] = ar; a.acc_rows[1] = ar - c->p.ny; a.acc_rows[2] = ar + c->p.ny;
+        switch ((int)(c->variant & (lbm::kFastMath | lbm::kNtStore))) {
+          case 0: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 0, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
+          case 1: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 1, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
+          case 2: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 2, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
+          default: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 3, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
+        }
+        HIPC(hipGetLastError());
+        if ((rc = raise(s, seq))) return rc;
+      }
+      c->cur ^= 1;
+    }
+    for (auto& s : c->slabs) {
+      HIPC(hipSetDevice(s.dev));
+      const int nb = march_slab_blocks(c, s);
+      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(kMarchK), dim3(lbm::kBlock), 0, s.sc, s.partials[(li - 1) & 1], nb,
+                         s.sums + (tt - kMarchK), nb);
+      HIPC(hipGetLastError());
+    }
+  }
+  // ---- the remaining steps trade halos: push those of the lattice as it stands
+  if (tt < nsteps) {
+    seq = ++c->seq;
+    for (auto& s : c->slabs) {
+      HIPC(hipSetDevice(s.dev));
+      if ((rc = push(s, s.lat[c->cur], seq, true))) return rc;
+    }
+  }
+  if (pairs && nsteps - tt >= 2) {
+    const int npairs = (nsteps - tt) / 2;
     for (int j = 0; j < npairs; ++j, ++li, tt += 2) {
       seq = ++c->seq;
       const int q = li & 1, qp = q ^ 1;
@@ -2088,7 +2233,8 @@ extern "C" int lbm_get_info(const lbm_ctx* c, const char* key, double* value) {
   if (!strcmp(key, "time_block")) { *value = c->time_block; return LBM_OK; }
   if (!strcmp(key, "t2_threads")) { *value = c->t2_threads; return LBM_OK; }
   if (!strcmp(key, "time_block_active")) {
-    *value = (march_eligible(c) || (c->exchange != 0 && march_slabs_on(const_cast<lbm_ctx*>(c)))) ? c->time_block : t2_eligible(c) ? 2 : 1;
+    *value = (march_eligible(c) || p2p_march_on(c) || (c->exchange != 0 && c->exchange != LBM_EXCHANGE_P2P && march_slabs_on(const_cast<lbm_ctx*>(c))))
+                 ? c->time_block : t2_eligible(c) ? 2 : 1;
     return LBM_OK;
   }
   if (!strcmp(key, "march_kernel")) { *value = (march_eligible(c) && use_wave_kernel(c)) ? 1 : 0; return LBM_OK; }

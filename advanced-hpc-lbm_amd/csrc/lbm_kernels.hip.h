@@ -820,6 +820,15 @@ __global__ __launch_bounds__(kBlock) void lbm_p2p_push(const float* lat, long pl
   }
 }
 
+// Peer-to-peer mode, marching launches: "launch group seq of this slab has finished" to both neighbours.  Runs on the
+// slab's stream right behind the launch it speaks for (the kernel boundary has released that launch's stores).
+__global__ void lbm_p2p_raise(uint32_t* rem_flag_s, uint32_t* rem_flag_n, uint32_t seq) {
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(rem_flag_s, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(rem_flag_n, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // Packs all nine halo slots of a resident lattice (start of a run).  Needs nyl >= 2.
 __global__ void lbm_pack_halos9(const float* lat, long plane, int pitch, int nx, int nyl,
                                 float* out_s, float* out_n) {

@@ -976,3 +976,88 @@ def test_default_engine_by_lattice(gpu):
             assert lat.info("engine_next") == want, n
             lat.run(3)
             assert lat.info("engine_last") == want, n
+
+
+@pytest.mark.parametrize("exchange", ["copy", "p2p"])
+@pytest.mark.parametrize("nx,ny,nslabs,steps", [(256, 64, 2, [4]), (256, 96, 3, [8, 5]), (480, 200, 4, [13]), (1024, 1024, 8, [16, 3])])
+def test_marching_kernel_across_slabs_of_one_process(gpu, exchange, nx, ny, nslabs, steps):
+    """lbm_march on row slabs: the K ghost rows either side are read straight out of the neighbouring slab's lattice
+    (no halo buffers), launches ordered by events (copy contexts) or by in-kernel flags (peer-to-peer contexts);
+    remainders of a run fall back to the halo-trading kernels.  Bit-identical to the undivided lattice."""
+    L = gpu
+    p, ob, cells = _random_case(L, nx, ny, 9)
+    with L.Lattice(p, ob, cells) as a:
+        a.set_option("time_block", 1)
+        av_a = np.concatenate([a.run(n) for n in steps])
+        st_a = a.read_state()
+    ex = L.EXCHANGE_COPY if exchange == "copy" else L.EXCHANGE_P2P
+    with L.Lattice(p, ob, cells, nslabs=nslabs, devices=[0] * nslabs, exchange=ex) as b:
+        b.set_option("time_block", 4)
+        assert b.info("time_block_active") == 4
+        av_b = np.concatenate([b.run(n) for n in steps])
+        st_b = b.read_state()
+    assert np.array_equal(st_a.view(np.uint32), st_b.view(np.uint32))
+    assert np.allclose(av_a, av_b, rtol=2e-6, atol=0)
+
+
+def _p2p_march_rank_worker(rank, nranks, shape, nsteps_list, conn, outdir):
+    import sys
+    for p_ in (ROOT, os.path.join(ROOT, "oracle")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    import advanced_hpc_lbm_amd as L
+    p, ob, cells = _random_case(L, shape[0], shape[1], 13)
+    lat = L.Lattice(p, ob, cells, rank=rank, nranks=nranks, device=0, unique_id=None, exchange=L.EXCHANGE_P2P)
+    lat.set_option("time_block", 4)
+    conn.send(lat.p2p_handle())
+    lat.p2p_connect(conn.recv())
+    assert lat.info("time_block_active") == 4
+    av = np.concatenate([lat.run(n) for n in nsteps_list])
+    np.save(os.path.join(outdir, f"av_{rank}.npy"), av)
+    np.save(os.path.join(outdir, f"state_{rank}.npy"), lat.read_state())
+    conn.send("done")
+    conn.recv()          # keep the lattices mapped until every rank has finished
+    lat.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_marching_kernel_between_processes(gpu, tmp_path, nranks):
+    """One process per slab (here sharing one GPU): each rank's lbm_march launches read the neighbouring ranks' rows out
+    of THEIR lattices, mapped through hipIpc handles that travel in the halo blocks; launches ordered by flags raised
+    by a one-thread kernel behind each launch.  Bit-identical to the undivided lattice; av_vels contributions add up."""
+    import multiprocessing as mp
+    L = gpu
+    shape, splits = (256, 96), [8, 5]
+    p, ob, cells = _random_case(L, shape[0], shape[1], 13)
+    with L.Lattice(p, ob, cells) as lat:
+        lat.set_option("time_block", 1)
+        av1 = np.concatenate([lat.run(n) for n in splits])
+        st1 = lat.read_state()
+    ctx = mp.get_context("spawn")
+    pipes = [ctx.Pipe() for _ in range(nranks)]
+    procs = [ctx.Process(target=_p2p_march_rank_worker, args=(r, nranks, shape, splits, pipes[r][1], str(tmp_path)))
+             for r in range(nranks)]
+    for pr in procs:
+        pr.start()
+    try:
+        handles = []
+        for r in range(nranks):
+            assert pipes[r][0].poll(120), f"rank {r} did not come up"
+            handles.append(pipes[r][0].recv())
+        for r in range(nranks):
+            pipes[r][0].send(handles)
+        for r in range(nranks):
+            assert pipes[r][0].poll(120), f"rank {r} did not finish"
+            assert pipes[r][0].recv() == "done"
+        for r in range(nranks):
+            pipes[r][0].send("bye")
+    finally:
+        for pr in procs:
+            pr.join(60)
+            if pr.is_alive():
+                pr.kill()
+    assert all(pr.exitcode == 0 for pr in procs)
+    av2 = sum(np.load(tmp_path / f"av_{r}.npy").astype(np.float64) for r in range(nranks))
+    st2 = np.concatenate([np.load(tmp_path / f"state_{r}.npy") for r in range(nranks)], axis=0)
+    assert np.array_equal(st1.view(np.uint32), st2.view(np.uint32))
+    assert np.allclose(av1, av2, rtol=2e-6, atol=0)
