@@ -158,6 +158,90 @@ def _worker_pairs(rank, world, port, deck, npairs, outdir):
         dist.destroy_process_group()
 
 
+def _worker_march(rank, world, port, deck, ngroups, K, outdir):
+    """K steps per exchange, the marching kernels' ghost zone: K whole rows of the neighbour either side (the HIP path
+    reads them in place out of the neighbour's lattice, here they travel over gloo), recomputed with shrinking reach;
+    everything a sub-step does not compute is NaN."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import advanced_hpc_lbm_amd as L
+    import lbm_oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = O.Oracle("strict")
+        pf, of = deck
+        gp = O.read_params(pf)
+        gob = O.read_obstacles(of, gp.nx, gp.ny)
+        nx, ny = gp.nx, gp.ny
+        r0, r1 = L.slab_bounds(ny, world, rank)
+        nyl = r1 - r0
+        south, north = L.ring_neighbours(rank, world)
+        ne = nyl + 2 * K                               # ext row e <-> slab row e - K <-> lattice row (r0 - K + e) mod ny
+        lp = O.OrcParam(nx, ne, gp.maxIters, gp.reynolds_dim, gp.density, gp.accel, gp.omega)
+        ob = np.stack([gob[(r0 - K + e) % ny] for e in range(ne)]).astype(np.int32)   # neighbours' obstacle rows: static
+        a = np.full((ne, nx, 9), np.nan)
+        a[K:K + nyl] = orc.init_cells(gp, np.float64)[r0:r1]
+        b = np.full_like(a, np.nan)
+        acc_rows = [e for e in range(ne) if (r0 - K + e) % ny == ny - 2]   # the accelerate row and its images in the ghost zone
+        av = np.zeros(K * ngroups)
+        for g in range(ngroups):
+            a[:K] = np.nan
+            a[K + nyl:] = np.nan
+            send_s = torch.from_numpy(np.ascontiguousarray(a[K:2 * K]))              # my bottom K rows -> the south's northern ghost
+            send_n = torch.from_numpy(np.ascontiguousarray(a[nyl:nyl + K]))          # my top K rows -> the north's southern ghost
+            recv_n, recv_s = torch.empty_like(send_s), torch.empty_like(send_n)
+            reqs = [dist.isend(send_s, south, tag=1), dist.isend(send_n, north, tag=2),
+                    dist.irecv(recv_n, north, tag=1), dist.irecv(recv_s, south, tag=2)]
+            for r in reqs:
+                r.wait()
+            a[K + nyl:] = recv_n.numpy()
+            a[:K] = recv_s.numpy()
+            for s_ in range(1, K + 1):                 # sub-step s_ is valid on ext rows [s_, ne - s_)
+                for e in acc_rows:
+                    if s_ - 1 <= e < ne - (s_ - 1):    # (a row of the current state that is still valid)
+                        orc.accelerate_row(lp, a, ob, e)
+                b[:] = np.nan
+                if s_ < K:
+                    orc.sweep_rows(lp, a, b, ob, s_, K)
+                    orc.sweep_rows(lp, a, b, ob, K + nyl, ne - s_)
+                tot, cnt = orc.sweep_rows(lp, a, b, ob, K, K + nyl)
+                red = torch.tensor([tot, float(cnt)], dtype=torch.float64)
+                dist.all_reduce(red)
+                av[g * K + s_ - 1] = red[0].item() / red[1].item()
+                a, b = b, a
+        np.save(os.path.join(outdir, f"state_{rank}.npy"), a[K:K + nyl])
+        np.save(os.path.join(outdir, f"av_{rank}.npy"), av)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,deck,ngroups,K", [(2, "128x256", 6, 4), (2, "128x128", 6, 4), (3, "128x128", 4, 4), (2, "128x256", 3, 6)])
+def test_k_row_ghost_zone_of_the_marching_kernels(tmp_path, O, oracle, world, deck, ngroups, K):
+    """K steps on a slab need K rows of each neighbour and nothing else (accelerate row included, wherever in the ghost
+    zone its periodic image falls): what lbm_march reads in place across slabs (lbm_api.hip: launch_march_slabs, run_p2p),
+    rehearsed with the oracle over gloo, NaN everywhere the algorithm does not compute."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.start_processes(_worker_march, args=(world, port, deck_paths(deck), ngroups, K, str(tmp_path)),
+                       nprocs=world, join=True, start_method="spawn")
+    pf, of = deck_paths(deck)
+    prm = O.read_params(pf)
+    ob = O.read_obstacles(of, prm.nx, prm.ny)
+    cells = oracle.init_cells(prm, np.float64)
+    av = oracle.run(prm, cells, ob, K * ngroups)
+    import advanced_hpc_lbm_amd as L
+    for r in range(world):
+        r0, r1 = L.slab_bounds(prm.ny, world, r)
+        got = np.load(tmp_path / f"state_{r}.npy")
+        assert np.array_equal(got, cells[r0:r1]), f"slab {r} differs from the single-domain lattice"
+        assert np.allclose(np.load(tmp_path / f"av_{r}.npy"), av, rtol=1e-12, atol=0)
+
+
 @pytest.mark.parametrize("world,deck,npairs", [(2, "128x256", 15), (2, "128x128", 15), (3, "128x128", 8)])
 def test_two_step_halo_protocol_matches_single_domain_oracle(tmp_path, O, oracle, world, deck, npairs):
     """The nine-slot halo of the two-step kernel (HALO9_*): exchanged once per pair of steps, ring rows
