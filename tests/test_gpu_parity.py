@@ -706,6 +706,7 @@ def test_big_slabs_run_edges_on_their_own_stream(gpu):
         av1 = np.concatenate([lat.run(12), lat.run(7)])
         f1 = lat.final_state()
     with L.Lattice(p, ob, nslabs=2, devices=[0, 0], exchange=L.EXCHANGE_COPY) as lat:
+        lat.set_option("time_block", 2)      # the default here is the marching kernel, which has no edge stream
         assert lat.info("time_block_active") == 2
         av2 = np.concatenate([lat.run(12), lat.run(7)])
         f2 = lat.final_state()
