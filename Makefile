@@ -23,18 +23,21 @@ all: $(EXE)
 
 lib: $(LIB)
 
-$(LIB): $(PKG)/csrc/lbm_api.hip $(PKG)/csrc/lbm_kernels.hip.h $(PKG)/csrc/lbm_resident.hip.h $(PKG)/csrc/lbm_march.hip.h $(PKG)/csrc/lbm_wave.hip.h $(PKG)/csrc/lbm_regtile.hip.h include/lbm_mi355x.h
+$(LIB): $(PKG)/csrc/lbm_api.hip $(PKG)/csrc/lbm_kernels.hip.h $(PKG)/csrc/lbm_exact_math.hip.h $(PKG)/csrc/lbm_resident.hip.h $(PKG)/csrc/lbm_march.hip.h $(PKG)/csrc/lbm_wave.hip.h $(PKG)/csrc/lbm_regtile.hip.h include/lbm_mi355x.h
 	$(HIPCC) $(HIPFLAGS) -shared $< -o $@ -ldl -Wl,-rpath,/opt/rocm/lib
 
 $(EXE): $(PKG)/host/d2q9-bgk.c $(LIB) include/lbm_mi355x.h
 	$(CC) $(CFLAGS) -Iinclude $< -o $@ -L$(PKG) -llbm_mi355x -Wl,-rpath,'$$ORIGIN/$(PKG)' -Wl,-rpath,/opt/rocm/lib
 
-tools: tools/kbench tools/layout_bench
+tools: tools/kbench tools/layout_bench tools/exact_math_check
 
 tools/layout_bench: tools/layout_bench.hip
 	$(HIPCC) $(HIPFLAGS) $< -o $@
 
-tools/kbench: tools/kbench.hip $(PKG)/csrc/lbm_kernels.hip.h
+tools/exact_math_check: tools/exact_math_check.hip $(PKG)/csrc/lbm_exact_math.hip.h
+	$(HIPCC) $(HIPFLAGS) $< -o $@
+
+tools/kbench: tools/kbench.hip $(PKG)/csrc/lbm_kernels.hip.h $(PKG)/csrc/lbm_exact_math.hip.h
 	$(HIPCC) $(HIPFLAGS) $< -o $@
 
 oracle:
@@ -46,4 +49,4 @@ check:
 .PHONY: all lib tools oracle check clean
 
 clean:
-	rm -f $(EXE) $(LIB) tools/kbench tools/layout_bench
+	rm -f $(EXE) $(LIB) tools/kbench tools/layout_bench tools/exact_math_check

@@ -137,7 +137,8 @@ struct Slab {
   float* partials[2] = {nullptr, nullptr};
   int partial_cap = 0;
   double* sums = nullptr;      // one double per step of the current run
-  double* sums_host = nullptr; // pinned staging for the same (one async copy at the end of a run)
+  double* sums_host = nullptr; // pinned host copy of the same
+  bool sums_direct = false;    // the kernels write the sums straight into sums_host (sums aliases it): no copy at the end of a run
   int sums_cap = 0;
   uint32_t* err_host = nullptr;  // pinned: copy of the peer-to-peer error word, fetched with the sums
   double* scratch_d = nullptr; // small double scratch (derive / reductions)
@@ -542,7 +543,7 @@ void slab_free(Slab& s) {
     if (s.ev_int[i]) (void)hipEventDestroy(s.ev_int[i]);
   }
   if (s.blocked) (void)hipFree(s.blocked);
-  if (s.sums) (void)hipFree(s.sums);
+  if (s.sums && !s.sums_direct) (void)hipFree(s.sums);
   if (s.sums_host) (void)hipHostFree(s.sums_host);
   if (s.err_host) (void)hipHostFree(s.err_host);
   if (s.scratch_d) (void)hipFree(s.scratch_d);
@@ -647,20 +648,28 @@ int exchange_halos(lbm_ctx* c, int q, int slot0, int nslots) {
   return LBM_OK;
 }
 
-// Per-step sums of a run: device array + pinned host staging.  Sized once at lbm_create for the
-// deck's own maxIters and grown geometrically, so that a run never allocates unless it is longer
-// than anything before it (an allocation inside lbm_run costs more than a 20-step run of 1024^2).
+// Per-step sums of a run.  Sized once at lbm_create for the deck's own maxIters and grown
+// geometrically, so that a run never allocates unless it is longer than anything before it (an
+// allocation inside lbm_run costs more than a 20-step run of 1024^2).  Where no collective reduces
+// them on the device (every context but a rank of a process-per-GPU job), the folding blocks store
+// each step's double straight into pinned host memory -- one posted 8-byte write per step -- and a
+// run ends without a device-to-host copy (two queued copies cost ~10 us of a 150-us 20-step run);
+// a rank keeps a device array (RCCL reduces it) and a pinned staging copy.
 int ensure_sums(Slab& s, int nsteps) {
   if (s.sums_cap >= nsteps) return LBM_OK;
   HIPC(hipSetDevice(s.dev));
   int cap = std::max(1024, s.sums_cap);
   while (cap < nsteps) cap = (cap > (1 << 29)) ? nsteps : cap * 2;
-  if (s.sums) HIPC(hipFree(s.sums));
+  if (s.sums && !s.sums_direct) HIPC(hipFree(s.sums));
   if (s.sums_host) HIPC(hipHostFree(s.sums_host));
   s.sums = nullptr; s.sums_host = nullptr; s.sums_cap = 0;
-  HIPC(hipMalloc((void**)&s.sums, sizeof(double) * cap));
-  HIPC(hipHostMalloc((void**)&s.sums_host, sizeof(double) * cap, hipHostMallocDefault));
-  if (!s.err_host) { HIPC(hipHostMalloc((void**)&s.err_host, 64, hipHostMallocDefault)); *s.err_host = 0; }
+  HIPC(hipHostMalloc((void**)&s.sums_host, sizeof(double) * cap, hipHostMallocPortable | hipHostMallocMapped));
+  if (s.sums_direct) HIPC(hipHostGetDevicePointer((void**)&s.sums, s.sums_host, 0));
+  else HIPC(hipMalloc((void**)&s.sums, sizeof(double) * cap));
+  if (!s.err_host) {
+    HIPC(hipHostMalloc((void**)&s.err_host, 64, hipHostMallocPortable | hipHostMallocMapped));
+    memset(s.err_host, 0, 64);
+  }
   s.sums_cap = cap;
   return LBM_OK;
 }
@@ -680,6 +689,7 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
     if (rc) return rc;
     rc = slab_upload(c, s, obstacles, cells);
     if (rc) return rc;
+    s.sums_direct = !c->rank_mode;
     rc = ensure_sums(s, std::max(c->p.maxIters, 1));
     if (rc) return rc;
   }
@@ -1393,9 +1403,8 @@ int collect_sums(lbm_ctx* c, int nsteps, float* av_vels, std::chrono::steady_clo
   }
   for (auto& s : c->slabs) {
     HIPC(hipSetDevice(s.dev));
-    if (av_vels) HIPC(hipMemcpyAsync(s.sums_host, s.sums, sizeof(double) * nsteps, hipMemcpyDeviceToHost, s.sc));
+    if (av_vels && !s.sums_direct) HIPC(hipMemcpyAsync(s.sums_host, s.sums, sizeof(double) * nsteps, hipMemcpyDeviceToHost, s.sc));
     if (s.counters) HIPC(hipMemcpyAsync(s.err_host, s.counters + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, s.sc));
-    if (c->rabort && &s == &c->slabs[0]) HIPC(hipMemcpyAsync(s.err_host + 1, c->rabort, sizeof(uint32_t), hipMemcpyDeviceToHost, s.sc));
   }
   double gpu_ms = 0.0;
   for (auto& s : c->slabs) {
@@ -1540,6 +1549,7 @@ int run_resident(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
   a.mail = c->rmail; a.partials = c->rpartials; a.abort_word = c->rabort;
   c->rtag += (uint32_t)nsteps;
 
+  s.err_host[1] = 0;   // lbm_fold_steps stores the abort word here
   const auto wall0 = std::chrono::steady_clock::now();
   HIPC(hipEventRecord(s.ev_t0, s.sc));
   switch (r.v) {
@@ -1549,10 +1559,9 @@ int run_resident(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
   }
   HIPC(hipGetLastError());
   hipLaunchKernelGGL(lbm::lbm_fold_steps, dim3(cdiv(nsteps, lbm::kBlock / 64)), dim3(lbm::kBlock), 0, s.sc,
-                     c->rpartials, ntiles, nsteps, s.sums);
+                     c->rpartials, ntiles, nsteps, s.sums, c->rabort, s.err_host + 1);
   HIPC(hipGetLastError());
   HIPC(hipEventRecord(s.ev_t1, s.sc));
-  s.err_host[1] = 0;
   rc = collect_sums(c, nsteps, av_vels, wall0);
   if (rc) return rc;
   if (s.err_host[1] != 0) {
@@ -1571,8 +1580,9 @@ int run_resident(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
 bool regtile_ok(const lbm_ctx* c, int ty, int r) {
   if (c->p.nx % 64 != 0 || ty < 1 || ty > c->p.ny || c->p.ny % ty != 0) return false;
   if (!(r == 1 || r == 2 || r == 4) || ty % r != 0 || ty / r > 16) return false;
-  // every tile must be resident at once: a CU takes 16 waves of this kernel (128 VGPRs) and three of its 49-KB LDS blocks
-  const int per_cu = std::min(3, 16 / (ty / r));
+  // every tile must be resident at once: a CU takes 16 waves of this kernel (128 VGPRs) and 160 KB of its blocks' LDS
+  const int nw = ty / r;
+  const int per_cu = std::min({3, 16 / nw, (160 * 1024) / lbm::regtile_lds_bytes(nw, r)});
   return (long)(c->p.nx / 64) * (c->p.ny / ty) <= (long)c->ncu * per_cu;
 }
 void regtile_set(lbm_ctx* c, int ty, int r) {
@@ -1593,13 +1603,25 @@ bool plan_regtile(lbm_ctx* c) {
   return false;
 }
 
+// One launch of lbm_regtile<R, MODE>; its LDS is dynamic and may exceed the 64 KB a kernel gets without asking.
+template <int R, int MODE>
+void launch_regtile(dim3 grid, dim3 block, unsigned shm, hipStream_t st, const lbm::RegTileArgs& a) {
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbm::lbm_regtile<R, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    raised = true;
+  }
+  hipLaunchKernelGGL((lbm::lbm_regtile<R, MODE>), grid, block, shm, st, a);
+}
+
 int run_regtile(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
   *done = false;
   Slab& s = c->slabs[0];
   HIPC(hipSetDevice(s.dev));
   const auto& t = c->tplan;
   const int ntiles = t.ntx * t.nty;
-  const size_t mail_bytes = sizeof(unsigned long long) * (size_t)ntiles * 2 * (size_t)lbm::regtile_box(t.ty);
+  const size_t mail_bytes = (size_t)ntiles * 2 * (size_t)lbm::regtile_box(t.ty);
   if (!c->tmail) {
     HIPC(hipMalloc((void**)&c->tmail, mail_bytes));
     HIPC(hipMemsetAsync(c->tmail, 0, mail_bytes, s.sc));
@@ -1633,32 +1655,72 @@ int run_regtile(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
   a.a1 = c->p.density * c->p.accel / 9.f; a.a2 = c->p.density * c->p.accel / 36.f;
   a.ty = t.ty; a.ntx = t.ntx; a.nty = t.nty;
   a.nsteps = nsteps; a.tag0 = c->rtag;
-  a.mail = c->tmail; a.partials = c->rpartials; a.abort_word = c->rabort;
-  c->rtag += (uint32_t)nsteps;
+  a.mail = c->tmail; a.mail_bytes = (unsigned)mail_bytes; a.partials = c->rpartials; a.abort_word = c->rabort;
+  a.stats = nullptr;
+  static const bool want_stats = getenv("LBM_REGTILE_STATS") != nullptr;   // development: missed polls per run, and a trace
+  static unsigned long long* stats_buf = nullptr;
+  constexpr size_t kStatsWords = 4 + 16 * 4 * 16;
+  if (want_stats) {
+    if (!stats_buf) HIPC(hipMalloc((void**)&stats_buf, kStatsWords * 8));
+    unsigned long long head[4] = {0, 0, (unsigned long long)(getenv("LBM_REGTILE_TRACE_TILE") ? atoi(getenv("LBM_REGTILE_TRACE_TILE")) : ntiles / 2 + t.ntx / 2),
+                                  (unsigned long long)(getenv("LBM_REGTILE_TRACE_STEP") ? atoi(getenv("LBM_REGTILE_TRACE_STEP")) : nsteps / 2)};
+    HIPC(hipMemsetAsync(stats_buf, 0, kStatsWords * 8, s.sc));
+    HIPC(hipMemcpyAsync(stats_buf, head, sizeof head, hipMemcpyHostToDevice, s.sc));
+    HIPC(hipStreamSynchronize(s.sc));
+    a.stats = stats_buf;
+  }
+  c->rtag += (uint32_t)nsteps + 1u;   // (the last step's mail is sent too, and must never be taken for the next run's state 0)
+  s.err_host[1] = 0;   // lbm_fold_steps stores the abort word here
   const auto wall0 = std::chrono::steady_clock::now();
   HIPC(hipEventRecord(s.ev_t0, s.sc));
   const bool fast = (c->variant & lbm::kFastMath) != 0;
   const dim3 grid(ntiles), block(64 * t.nw);
+  const unsigned shm = (unsigned)lbm::regtile_lds_bytes(t.nw, t.r);
   const char* dbg = getenv("LBM_RESIDENT_DEBUG");   // timing experiments (wrong results): see lbm_regtile.hip.h
   const int dv = dbg ? atoi(dbg) : 0;
-  if (dv >= 1 && dv <= 3 && t.r == 4) {
-    if (dv == 1) hipLaunchKernelGGL((lbm::lbm_regtile<4, 1 | lbm::kResDebugNoWait>), grid, block, 0, s.sc, a);
-    if (dv == 2) hipLaunchKernelGGL((lbm::lbm_regtile<4, 1 | lbm::kResDebugNoWait | lbm::kResDebugNoSend>), grid, block, 0, s.sc, a);
-    if (dv == 3) hipLaunchKernelGGL((lbm::lbm_regtile<4, 1 | lbm::kResDebugNoWait | lbm::kResDebugNoSend | 256>), grid, block, 0, s.sc, a);
+  if (dv >= 1 && dv <= 5 && t.r == 4) {
+    constexpr int NW_ = lbm::kResDebugNoWait, NS_ = lbm::kResDebugNoSend;
+    if (dv == 1) launch_regtile<4, NW_>(grid, block, shm, s.sc, a);
+    if (dv == 2) launch_regtile<4, NW_ | NS_>(grid, block, shm, s.sc, a);
+    if (dv == 3) launch_regtile<4, NW_ | NS_ | 256>(grid, block, shm, s.sc, a);
+    if (dv == 4) launch_regtile<4, NW_ | 512>(grid, block, shm, s.sc, a);
+    if (dv == 5) launch_regtile<4, NW_ | 1024>(grid, block, shm, s.sc, a);
+  } else if (t.r == 4 && want_stats && getenv("LBM_REGTILE_TRACE")) {
+    launch_regtile<4, 2048>(grid, block, shm, s.sc, a);
   } else
   switch (t.r) {
-    case 4: if (fast) hipLaunchKernelGGL((lbm::lbm_regtile<4, 1>), grid, block, 0, s.sc, a); else hipLaunchKernelGGL((lbm::lbm_regtile<4, 0>), grid, block, 0, s.sc, a); break;
-    case 2: if (fast) hipLaunchKernelGGL((lbm::lbm_regtile<2, 1>), grid, block, 0, s.sc, a); else hipLaunchKernelGGL((lbm::lbm_regtile<2, 0>), grid, block, 0, s.sc, a); break;
-    default: if (fast) hipLaunchKernelGGL((lbm::lbm_regtile<1, 1>), grid, block, 0, s.sc, a); else hipLaunchKernelGGL((lbm::lbm_regtile<1, 0>), grid, block, 0, s.sc, a); break;
+    case 4: if (fast) launch_regtile<4, 1>(grid, block, shm, s.sc, a); else launch_regtile<4, 0>(grid, block, shm, s.sc, a); break;
+    case 2: if (fast) launch_regtile<2, 1>(grid, block, shm, s.sc, a); else launch_regtile<2, 0>(grid, block, shm, s.sc, a); break;
+    default: if (fast) launch_regtile<1, 1>(grid, block, shm, s.sc, a); else launch_regtile<1, 0>(grid, block, shm, s.sc, a); break;
   }
   HIPC(hipGetLastError());
   hipLaunchKernelGGL(lbm::lbm_fold_steps, dim3(cdiv(nsteps, lbm::kBlock / 64)), dim3(lbm::kBlock), 0, s.sc,
-                     c->rpartials, ntiles, nsteps, s.sums);
+                     c->rpartials, ntiles, nsteps, s.sums, c->rabort, s.err_host + 1);
   HIPC(hipGetLastError());
   HIPC(hipEventRecord(s.ev_t1, s.sc));
-  s.err_host[1] = 0;
   rc = collect_sums(c, nsteps, av_vels, wall0);
   if (rc) return rc;
+  if (want_stats) {
+    std::vector<unsigned long long> st(kStatsWords);
+    HIPC(hipMemcpy(st.data(), stats_buf, kStatsWords * 8, hipMemcpyDeviceToHost));
+    fprintf(stderr, "lbm_regtile: %d steps, %d waves: %llu waits found their mail missing (%.3f per wave and step), %llu extra fetches\n",
+            nsteps, ntiles * t.nw, st[0], (double)st[0] / ((double)nsteps * ntiles * t.nw), st[1]);
+    if (getenv("LBM_REGTILE_TRACE")) {
+      unsigned long long t0 = ~0ull;
+      for (size_t i = 4; i < kStatsWords; ++i) if (st[i] && st[i] < t0) t0 = st[i];
+      fprintf(stderr, "trace of tile %llu from step %llu (shader clocks / 100 since the first stamp; slots: barrier | per row: start, mail, done | end)\n", st[2], st[3]);
+      for (int ww = 0; ww < t.nw; ++ww)
+        for (int q = 0; q < 4; ++q) {
+          fprintf(stderr, "  wave %2d step +%d:", ww, q);
+          for (int k = 0; k < 14; ++k) {
+            const unsigned long long v = st[4 + ((ww * 4 + q) * 16 + k)];
+            if (k == 1 || k == 13 || (k > 1 && (k - 1) % 3 == 0)) fprintf(stderr, " |");
+            fprintf(stderr, " %6.1f", v ? (double)(v - t0) / 100.0 : -1.0);
+          }
+          fprintf(stderr, "\n");
+        }
+    }
+  }
   if (s.err_host[1] != 0) {
     c->resident_broken = true;
     HIPC(hipMemsetAsync(c->rabort, 0, 64, s.sc));

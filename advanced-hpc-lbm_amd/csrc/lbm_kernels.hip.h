@@ -29,6 +29,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "lbm_exact_math.hip.h"
 
 namespace lbm {
 
@@ -93,11 +94,12 @@ constexpr int kNtLoad = 4;     // nontemporal loads of the source lattice
 constexpr int kBenchNoMath = 8;        // tools/kbench only: pull + store, no collision (wrong results)
 constexpr int kBenchAlignedOnly = 16;  // tools/kbench only: unshifted loads everywhere (wrong results)
 
+// (not FAST: correctly rounded, by the short sequences of lbm_exact_math.hip.h wherever they are proven)
 template <bool FAST> __device__ __forceinline__ float recip(float x) {
-  if constexpr (FAST) return __builtin_amdgcn_rcpf(x); else return 1.0f / x;
+  if constexpr (FAST) return __builtin_amdgcn_rcpf(x); else return recip_exact(x);
 }
 template <bool FAST> __device__ __forceinline__ float root(float x) {
-  if constexpr (FAST) return __builtin_amdgcn_sqrtf(x); else return sqrtf(x);
+  if constexpr (FAST) return __builtin_amdgcn_sqrtf(x); else return root_exact(x);
 }
 
 // One cell: p[] holds the nine pulled values on entry and the nine values to

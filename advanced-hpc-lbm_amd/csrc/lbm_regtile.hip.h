@@ -11,24 +11,36 @@
 //                             wave's edge row, which it wrote to LDS at the end of the previous step
 //                             (3 planes x 64 floats each way, double-buffered by step parity:
 //                             ONE raw s_barrier per step, lgkmcnt only)
-//   across the tile border    lane 0 / lane 63 (west / east column) and wave 0 / wave NW-1 (south / north
-//                             row) take the three populations that enter the tile out of the tile's
-//                             mailbox in global memory: 8-byte {value, tag} granules (MI355X_MICROARCH.md,
-//                             Valid forms, R2: the data is the flag; one aligned sc1 store, sc1 loads, no
-//                             fence), polled until the tag says "state s"; and the same threads store
-//                             their new edge values into the neighbours' mailboxes, fire and forget --
+//   across the tile border    16-byte {three populations, tag} granules in the neighbours' mailboxes in
+//                             global memory (MI355X_MICROARCH.md, Valid forms, R2: the data is the flag --
+//                             one aligned sc1 store, sc1 loads, no fence), polled until the tag says
+//                             "state s".  A ROW of the tile's east / west column is one granule (lane 63 /
+//                             lane 0 stores the three populations that leave the tile there; lanes 0,1,2 /
+//                             63,62,61 fetch the granules of rows rho, rho-1, rho+1 and two DPP row shifts
+//                             bring the diagonal ones to the edge lane); a COLUMN of the tile's bottom /
+//                             top row is one granule per lane (waves 0 / NW-1).  One store and one load
+//                             instruction per row -- a memory instruction costs its issue slot whether one
+//                             lane is active or sixty-four -- through a buffer descriptor (32-bit offsets);
 //                             nothing in the loop waits for a store (no vmcnt wait, no __syncthreads).
-// The update is in place, row by row upwards, with three saved registers (the old planes 2,5,6 of the row
-// just overwritten).  Mailbox of a tile, per parity: Sin / Nin [3 planes][64 columns] (from the tile
-// below / above), Win / Ein [3 planes][TY + 2 rows] (rows -1 .. TY: the two extra rows are the corner
-// populations, written by the diagonal tiles).  Two parities suffice for the reason given in
-// lbm_resident.hip.h: the thread that consumes a granule owns the cell that produces the opposite one.
+// A hand-off through L2 takes about a microsecond (MI355X_MICROARCH.md, handoff-1to1), a fifth of a step of a
+// full tile, and the first form of this loop -- mail sent after the last row, polled before the first --
+// waited for all of it.  Now the mail travels ROW BY ROW: a row's granules leave as soon as the row is done,
+// and a row's mail is fetched while the row before it is being computed.  What makes that hide the hand-off
+// is the order of the rows: even waves sweep their rows upwards, odd waves downwards (when the tile has an
+// even number of waves), so that rows which are neighbours in space -- across waves and across tiles -- are
+// at most one row apart in time, and every granule is R - 2 row-times old when it is needed.
+// The update is in place, with three saved registers (the old planes 2,5,6 -- going down: 4,7,8 -- of the
+// row just overwritten).  Mailbox of a tile, per parity: Sin / Nin [64 columns] (from the tile below /
+// above), Win / Ein [TY + 2 rows] (rows -1 .. TY: the two extra rows are the diagonal tiles' corner rows).
+// Two parities suffice for the reason given in lbm_resident.hip.h: the thread that consumes a granule owns
+// the cell that produces the opposite one (a row's granule feeds rows rho-1, rho, rho+1 of the neighbour,
+// and the row is not recomputed before all three have been).
 // Every wait is bounded and watches a global abort word; a run that gives up leaves the source lattice
 // untouched and the host repeats it with the streaming kernels.
 #pragma once
 #include <type_traits>
 #include "lbm_kernels.hip.h"
-#include "lbm_resident.hip.h"   // gu64 / gu32, kResidentTimeoutTicks, lbm_fold_steps
+#include "lbm_resident.hip.h"   // gu32, kResidentTimeoutTicks, lbm_fold_steps
 
 namespace lbm {
 
@@ -40,26 +52,34 @@ struct RegTileArgs {
   int ntx, nty;                // tiles per lattice row (nx / 64) / column (ny / ty); gridDim.x = ntx * nty
   int nsteps;
   uint32_t tag0;               // tag of state 0 of this run; state s carries tag0 + s
-  unsigned long long* mail;    // [tile][parity][regtile_box(ty)] granules
+  void* mail;                  // [tile][parity][regtile_box(ty) bytes]
+  unsigned mail_bytes;
   float* partials;             // [nsteps][ntiles]
   uint32_t* abort_word;
+  unsigned long long* stats;   // development: [0] += waits that found their mail missing, [1] += extra fetches (or nullptr)
 };
 
-// granules of one mailbox (one tile, one parity): Sin[3][64], Nin[3][64], Win[3][ty+2], Ein[3][ty+2]
-__host__ __device__ constexpr int regtile_box(int ty) { return 2 * 3 * 64 + 2 * 3 * (ty + 2); }
+// LDS bytes of a block of nw waves with r rows per wave (see the kernel)
+__host__ __device__ constexpr int regtile_lds_bytes(int nw, int r) { return 4 * (nw * (2 * 6 * 64 + r * 3 * 64) + 2 * 16 + 16); }
 
-__device__ __forceinline__ float rt_west(float v) {   // lane i <- lane i-1
-  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float rt_east(float v) {   // lane i <- lane i+1
-  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130, 0xf, 0xf, true));
-}
+// bytes of one mailbox (one tile, one parity): Sin[64], Nin[64], Win[ty+2], Ein[ty+2] granules of 16 bytes
+__host__ __device__ constexpr int regtile_box(int ty) { return 16 * (2 * 64 + 2 * (ty + 2)); }
 
-// v (all lanes) with lane `LANE` replaced by the wave-uniform value s (this toolchain has the readlane builtin only)
-template <int LANE>
-__device__ __forceinline__ int rt_writelane(int v, int s) {
-  asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(LANE));
-  return v;
+typedef unsigned int rt_u4 __attribute__((ext_vector_type(4)));
+
+// lane i <- lane i-1 (wave_shr:1) / lane i+1 (wave_shl:1); the lane with no source keeps `edge`
+__device__ __forceinline__ float rt_west(float edge, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float rt_east(float edge, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+// lane i <- lane i+N / i-N inside its row of 16 lanes (row_shl:N / row_shr:N)
+template <int N> __device__ __forceinline__ float rt_row_shl(unsigned v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + N, 0xf, 0xf, false));
+}
+template <int N> __device__ __forceinline__ float rt_row_shr(unsigned v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xf, 0xf, false));
 }
 
 // blockDim.x = 64 NW; R rows per wave.
@@ -67,11 +87,19 @@ template <int R, int MODE>
 __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
   constexpr bool FAST = (MODE & kFastMath) != 0;
   // timing experiments only (wrong results), LBM_RESIDENT_DEBUG: 1 = one pass over the inbox, no waiting; 2 = also no
-  // stores to other tiles; 3 = also no inbox loads at all
+  // stores to other tiles; 3 = also no inbox loads at all; 4 = like 1, the stores issued but dropped by an empty buffer
+  // descriptor (what the instructions cost without their memory traffic); 5 = like 1, stores without sc1
   constexpr bool DBG_NOWAIT = (MODE & kResDebugNoWait) != 0, DBG_NOSEND = (MODE & kResDebugNoSend) != 0, DBG_NOLOAD = (MODE & 256) != 0;
-  // LDS: edge rows between the waves of the tile [parity][wave][6][64] + per-wave speed sums [parity][16] + abort word
-  __shared__ __attribute__((aligned(16))) float lds[2 * 16 * 6 * 64 + 2 * 16 + 16];
-  float* red = lds + 2 * 16 * 6 * 64;
+  constexpr bool DBG_DROP = (MODE & 512) != 0, DBG_PLAIN = (MODE & 1024) != 0;
+  constexpr bool TRACE = (MODE & 2048) != 0;     // development: time stamps of one tile's waves (LBM_REGTILE_TRACE)
+  static_assert(R == 1 || R == 2 || R == 4, "rows per wave");
+  // LDS (dynamic, regtile_lds_bytes(nw, R)): edge rows between the waves of the tile [parity][wave][6][64]; the
+  // populations no other row ever pulls from -- planes 0, 1, 3 of every row, [wave][R][3][64]: a row's own update is
+  // the only reader and writer, so they wait in LDS instead of twelve registers the loop does not have; per-wave
+  // speed sums [parity][16]; abort word
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int nw_ = (int)(blockDim.x >> 6);
+  float* red = lds + nw_ * (2 * 6 * 64 + R * 3 * 64);
   uint32_t* lds_abort = reinterpret_cast<uint32_t*>(red + 32);
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -80,207 +108,301 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
   int tile = blockIdx.x;
   if ((nt & 7) == 0) tile = (tile & 7) * (nt >> 3) + (tile >> 3);      // neighbouring tiles mostly share an XCD (speed only)
   const int by = tile / a.ntx, bx = tile - by * a.ntx;
-  const int TY = a.ty, BOX = regtile_box(TY);
+  const int TY = a.ty;
+  const unsigned BOX = (unsigned)regtile_box(TY);
   auto tile_of = [&](int dx, int dy) {
     int x = bx + dx, y = by + dy;
     x += (x < 0) ? a.ntx : 0; x -= (x >= a.ntx) ? a.ntx : 0;
     y += (y < 0) ? a.nty : 0; y -= (y >= a.nty) ? a.nty : 0;
     return y * a.ntx + x;
   };
-  // mailbox sections (granule offsets inside a box)
-  const int oS = 0, oN = 3 * 64, oW = 6 * 64, oE = 6 * 64 + 3 * (TY + 2);
-  auto box = [&](int t, int parity) { return (gu64*)a.mail + (unsigned)((t * 2 + parity) * BOX); };   // (a few MB: 32-bit offsets)
-  auto send = [&](gu64* g, uint32_t tag, float v) {
-    if (!DBG_NOSEND) __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // mailbox sections (byte offsets inside a box); the whole mail area is a few MB: 32-bit offsets behind one descriptor
+  const unsigned oS = 0u, oN = 1024u, oW = 2048u, oE = 2048u + 16u * (unsigned)(TY + 2);
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.mail, 0, (int)a.mail_bytes, 0x00020000);
+  const auto rsrc_st = DBG_DROP ? __builtin_amdgcn_make_buffer_rsrc(a.mail, 0, 0, 0x00020000) : rsrc;
+  auto box = [&](int t) { return (unsigned)(t * 2) * BOX; };            // parity 0; parity 1: + BOX
+  // (per-lane offset in a register, wave-uniform offset in the instruction's scalar operand: one register per KIND of access)
+  auto send = [&](unsigned voff, unsigned soff, float v0, float v1, float v2, uint32_t tag) {
+    rt_u4 g;
+    g.x = __float_as_uint(v0); g.y = __float_as_uint(v1); g.z = __float_as_uint(v2); g.w = tag;
+    if (!DBG_NOSEND) __builtin_amdgcn_raw_buffer_store_b128(g, rsrc_st, voff, soff, DBG_PLAIN ? 0 : 16);      // aux 16 = sc1
   };
+  auto load = [&](unsigned voff, unsigned soff) { return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 16); };
   const int tS = tile_of(0, -1), tN = tile_of(0, 1), tW = tile_of(-1, 0), tE = tile_of(1, 0);
   const int tSW = tile_of(-1, -1), tSE = tile_of(1, -1), tNW = tile_of(-1, 1), tNE = tile_of(1, 1);
   const bool first = (w == 0), last = (w == nw - 1);
+  const bool down = ((nw & 1) == 0) && ((w & 1) != 0);      // this wave sweeps its rows downwards
   const int rho0 = w * R;                                   // tile row of this wave's first row
   const int gx = bx * 64 + lane, gy0 = by * TY + rho0;
   if (tid == 0) *lds_abort = 0u;
+  float* own = lds + nw * (2 * 6 * 64) + w * (R * 3 * 64) + lane;   // own[(r * 3 + j) * 64]: plane {0,1,3}[j] of row r
 
-  // ---- east / west mail in ONE store and ONE load instruction per wave and step (a memory instruction costs
-  // its issue slot whether one lane is active or sixty-four, and it was ~390 one-lane instructions per tile and
-  // step that made the first version of this loop memory-instruction bound).  Lane i of the wave is a courier:
-  //   i in [0, 3R)       slot i / R, row i % R of the EAST column (lane 63's planes 1,5,8) -> west inbox of the tile to the east
-  //   i in [3R, 6R)      the same of the WEST column (lane 0's planes 3,6,7)              -> east inbox of the tile to the west
-  //   6R .. 6R+3         the four corner populations (edge waves only)
-  // and on the way in lane i fetches the granule that lane 0 (i < 3R) or lane 63 needs for the same slot / row.
-  constexpr int NM = 3 * R;
-  unsigned send_off = 0u, recv_off = 0u;       // granule index inside a.mail for parity 0 (parity 1: + BOX)
-  bool send_on = false, recv_on = false;
-  {
-    const int i = lane % NM, side = lane / NM;              // side 0: east column, 1: west column
-    const int slot = i / R, r = i % R;
-    if (lane < 2 * NM) {
-      send_on = recv_on = true;
-      send_off = (unsigned)(((side == 0 ? tE : tW) * 2) * BOX + (side == 0 ? oW : oE) + slot * (TY + 2) + (rho0 + 1) + r);
-      // what the edge lane of row r needs: slot 0 of row rho, slot 1 of row rho-1, slot 2 of row rho+1 (inbox row index = row + 1)
-      recv_off = (unsigned)((tile * 2) * BOX + (side == 0 ? oW : oE) + slot * (TY + 2) + (rho0 + 1) + r + (slot == 1 ? -1 : slot == 2 ? 1 : 0));
-    } else if (lane < 2 * NM + 4) {
-      const int c = lane - 2 * NM;                          // 0: NE (plane 5 of the top row), 1: NW (6), 2: SE (8 of the bottom row), 3: SW (7)
-      send_on = (c < 2) ? last : first;
-      const int t = (c == 0) ? tNE : (c == 1) ? tNW : (c == 2) ? tSE : tSW;
-      const int sec = (c == 0 || c == 2) ? oW : oE;
-      send_off = (unsigned)((t * 2) * BOX + sec + (c < 2 ? (TY + 2) + 0 : 2 * (TY + 2) + (TY + 1)));
-    }
+  // east / west mail: lane 63 stores its row into the west inbox of the tile to the east, lane 0 into the east inbox of
+  // the tile to the west (inbox row index = tile row + 1); lanes 0,1,2 fetch rows rho, rho-1, rho+1 of this tile's west
+  // inbox, lanes 63,62,61 of its east inbox.  Offsets for row 0 of the wave, parity 0.
+  const bool edge_lane = (lane == 0) || (lane == 63);
+  const bool courier = (lane < 3) || (lane > 60);
+  // The mail LOADS of the loop are issued by every lane of every wave, unconditionally: the lanes (and waves) a load
+  // does not concern carry an offset beyond the end of the buffer, and the descriptor's range check answers them
+  // with zeros.  The STORES stay behind their branches (lanes 0 and 63, the tile's first and last wave): with stores
+  // masked the same way the lattice came out wrong once a SIMD held more than one wave of the tile.  A branch with a
+  // memory operation in it makes the compiler wait for ALL outstanding memory operations (s_waitcnt vmcnt(0)) the
+  // next time a loaded value is used behind it, acknowledgements of the sc1 stores included (~1500 cycles) -- so
+  // a row's granules are sent only once the NEXT row's mail has been waited for (do_row): no load is ever in flight
+  // across the stores, and the stores have a whole row's arithmetic to complete in.
+  constexpr unsigned OOB = 0x80000000u;
+  const unsigned lane16 = 16u * (unsigned)lane;
+  const unsigned ew_voff = ((lane == 0) ? box(tW) + oE : box(tE) + oW) + 16u * (unsigned)(rho0 + 1);   // (lanes 0 and 63)
+  unsigned rv_voff = OOB;
+  if (courier) {
+    const int d = (lane < 3) ? lane : 63 - lane;            // 0: row rho, 1: rho-1, 2: rho+1
+    rv_voff = ((lane < 3) ? oW : oE) + 16u * (unsigned)(rho0 + 1 + (d == 1 ? -1 : d == 2 ? 1 : 0));   // (+ box(tile): scalar)
   }
-  static_assert(2 * NM + 4 <= 64, "couriers must fit a wave");
+  const unsigned first_voff = first ? lane16 : OOB, last_voff = last ? lane16 : OOB;     // the tile's bottom / top row
+  const unsigned cs_voff = ((lane == 0) ? box(tSW) + oE : box(tSE) + oW) + 16u * (unsigned)(TY + 1);    // its corners (lanes 0 and 63)
+  const unsigned cn_voff = (lane == 0) ? box(tNW) + oE : box(tNE) + oW;
+  const unsigned mybox = __builtin_amdgcn_readfirstlane(box(tile));
 
   // ---- state 0
-  float f[R][9];
+  float f[R][9];               // (planes 0, 1, 3 live in `own`: those elements are never used)
   bool blk[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const long o = (long)(gy0 + r) * a.pitch + gx;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) f[r][k] = a.src[k * a.plane + o];
-    blk[r] = a.blocked[o] != 0;
-    if (gy0 + r == a.accel_row) accelerate_cell(f[r], blk[r], a.a1, a.a2);   // accelerate phase of the first step
-  }
 
-  // publish the edge values of the state in f: LDS rows for the neighbouring waves, granules for the
-  // neighbouring tiles
-  auto publish = [&](uint32_t tag, int parity) {
-    if (first) {            // the tile's bottom row enters the tile below through ITS north inbox
-      gu64* b = box(tS, parity) + oN + lane;
-      send(b, tag, f[0][4]); send(b + 64, tag, f[0][7]); send(b + 128, tag, f[0][8]);
-    }
-    if (last) {
-      gu64* b = box(tN, parity) + oS + lane;
-      send(b, tag, f[R - 1][2]); send(b + 64, tag, f[R - 1][5]); send(b + 128, tag, f[R - 1][6]);
-    }
-    // east / west columns and corners: lane transposition (readlane from the edge lane, writelane into the courier lane), one store
-    int sv = 0;
-    auto put = [&](auto lane_c, float v, int from) {
-      sv = rt_writelane<decltype(lane_c)::value>(sv, __builtin_amdgcn_readlane(__float_as_int(v), from));
-    };
-    auto put_rows = [&](auto slot_c) {
-      constexpr int slot = decltype(slot_c)::value;
-      constexpr int ke = (slot == 0) ? 1 : (slot == 1) ? 5 : 8, kw = (slot == 0) ? 3 : (slot == 1) ? 6 : 7;
-      put(std::integral_constant<int, slot * R + 0>{}, f[0][ke], 63);
-      put(std::integral_constant<int, NM + slot * R + 0>{}, f[0][kw], 0);
-      if constexpr (R > 1) { put(std::integral_constant<int, slot * R + 1>{}, f[1 % R][ke], 63); put(std::integral_constant<int, NM + slot * R + 1>{}, f[1 % R][kw], 0); }
-      if constexpr (R > 2) {
-        put(std::integral_constant<int, slot * R + 2>{}, f[2 % R][ke], 63); put(std::integral_constant<int, NM + slot * R + 2>{}, f[2 % R][kw], 0);
-        put(std::integral_constant<int, slot * R + 3>{}, f[3 % R][ke], 63); put(std::integral_constant<int, NM + slot * R + 3>{}, f[3 % R][kw], 0);
-      }
-    };
-    static_assert(R == 1 || R == 2 || R == 4, "rows per wave");
-    put_rows(std::integral_constant<int, 0>{});
-    put_rows(std::integral_constant<int, 1>{});
-    put_rows(std::integral_constant<int, 2>{});
-    put(std::integral_constant<int, 2 * NM + 0>{}, f[R - 1][5], 63);
-    put(std::integral_constant<int, 2 * NM + 1>{}, f[R - 1][6], 0);
-    put(std::integral_constant<int, 2 * NM + 2>{}, f[0][8], 63);
-    put(std::integral_constant<int, 2 * NM + 3>{}, f[0][7], 0);
-    if (send_on) send((gu64*)a.mail + (send_off + (unsigned)(parity * BOX)), tag, __int_as_float(sv));
-    float* me = lds + ((parity * 16 + w) * 6) * 64 + lane;
-    // bottom row's planes 4,7,8 for the wave below; top row's 2,5,6 for the wave above
+  // what a row hands to the neighbouring tiles, from the state in f (pb = parity x BOX)
+  auto send_row = [&](auto rc, uint32_t tag, unsigned pb, const float (&q)[9]) {   // q = the row's nine populations
+    constexpr int r = decltype(rc)::value;
+    if (r == 0 && first)             // the tile's bottom row enters the tile below through ITS north inbox
+      send(lane16, box(tS) + oN + pb, q[4], q[7], q[8], tag);
+    if (r == R - 1 && last)
+      send(lane16, box(tN) + oS + pb, q[2], q[5], q[6], tag);
+    const float e1 = q[1], e5 = q[5], e8 = q[8], w3 = q[3], w6 = q[6], w7 = q[7];
+    const bool wl = lane == 0;
+    const float v0 = wl ? w3 : e1, v1 = wl ? w6 : e5, v2 = wl ? w7 : e8;
+    if (edge_lane) send(ew_voff, pb + 16u * r, v0, v1, v2, tag);
+    // the tile's corners: the same granule is row -1 / row TY of the diagonal tile's inbox
+    if (r == R - 1 && last && edge_lane) send(cn_voff, pb, v0, v1, v2, tag);
+    if (r == 0 && first && edge_lane) send(cs_voff, pb, v0, v1, v2, tag);
+  };
+  // the edge rows of the state in f for the neighbouring waves: bottom row's planes 4,7,8, top row's 2,5,6
+  auto publish_lds = [&](int parity) {
+    float* me = lds + ((parity * nw + w) * 6) * 64 + lane;
     me[0 * 64] = f[0][4]; me[1 * 64] = f[0][7]; me[2 * 64] = f[0][8];
     me[3 * 64] = f[R - 1][2]; me[4 * 64] = f[R - 1][5]; me[5 * 64] = f[R - 1][6];
   };
-  publish(a.tag0, 0);
+
+  // the mail of one row: the couriers' granules (g); for the tile's bottom row the row below it (e), for its top row
+  // the row above (e -- or x where one row is both: R = 1 in a tile of one wave)
+  struct Mail { rt_u4 g, e, x; };
+  auto fetch = [&](auto rc, unsigned pb, Mail& m) {
+    constexpr int r = decltype(rc)::value;
+    if (DBG_NOLOAD) return;
+    m.g = load(rv_voff, mybox + pb + 16u * r);
+    if (r == 0) m.e = load(first_voff, mybox + oS + pb);
+    if (r == R - 1) {
+      if constexpr (R == 1) m.x = load(last_voff, mybox + oN + pb);
+      else m.e = load(last_voff, mybox + oN + pb);
+    }
+  };
+  auto arrived = [&](auto rc, const Mail& m, uint32_t want) {
+    constexpr int r = decltype(rc)::value;
+    bool ok = true;
+    if (courier) ok = m.g.w == want;
+    if ((r == 0 && first) || (R > 1 && r == R - 1 && last)) ok = ok && m.e.w == want;
+    if (R == 1 && last) ok = ok && m.x.w == want;
+    return __all(ok) != 0;
+  };
+  unsigned nmiss = 0u, nspin = 0u;
+  // development trace (a.stats != nullptr): shader-clock stamps of the waves of one tile over four steps,
+  // stats[2 + ((wave * 4 + step - s0) * 16 + slot)]
+  const bool tracing = TRACE && a.stats != nullptr && tile == (int)a.stats[2];
+  const int trace_s0 = (TRACE && a.stats != nullptr) ? (int)a.stats[3] : 0;
+  auto stamp = [&](int s, int slot) {
+    if constexpr (TRACE) {
+      if (tracing && s >= trace_s0 && s < trace_s0 + 4 && lane == 0)
+        a.stats[4 + ((w * 4 + (s - trace_s0)) * 16 + slot)] = __builtin_amdgcn_s_memtime();
+    }
+  };
+  auto await = [&](auto rc, unsigned pb, uint32_t want, Mail& m) {
+    if (DBG_NOLOAD || DBG_NOWAIT || arrived(rc, m, want)) return;
+    const long long t0 = wall_clock64();
+    ++nmiss;
+    for (;;) {
+      __builtin_amdgcn_s_sleep(1);
+      ++nspin;
+      fetch(rc, pb, m);
+      if (arrived(rc, m, want)) return;
+      if (wall_clock64() - t0 > kResidentTimeoutTicks ||
+          __hip_atomic_load((gu32*)a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        __hip_atomic_store((gu32*)a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *lds_abort = 1u;      // (this wave carries on with what it has; everybody leaves together behind the next barrier)
+        return;
+      }
+    }
+  };
+  auto blank = [&](Mail& m) { m.g = rt_u4{0u, 0u, 0u, 0u}; m.e = m.g; m.x = m.g; };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1 % R>;
+  using I2 = std::integral_constant<int, 2 % R>;
+  using I3 = std::integral_constant<int, 3 % R>;
+  using ILast = std::integral_constant<int, R - 1>;
+
+  // ---- state 0: loaded, and sent row by row like every other state
+  auto first_state = [&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    const long o = (long)(gy0 + r) * a.pitch + gx;
+    float q[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) q[k] = a.src[k * a.plane + o];
+    blk[r] = a.blocked[o] != 0;
+    if (gy0 + r == a.accel_row) accelerate_cell(q, blk[r], a.a1, a.a2);   // accelerate phase of the first step
+    f[r][2] = q[2]; f[r][4] = q[4]; f[r][5] = q[5]; f[r][6] = q[6]; f[r][7] = q[7]; f[r][8] = q[8];
+    own[(r * 3 + 0) * 64] = q[0]; own[(r * 3 + 1) * 64] = q[1]; own[(r * 3 + 2) * 64] = q[3];
+    send_row(rc, a.tag0, 0u, q);
+  };
+  first_state(I0{});
+  if constexpr (R > 1) first_state(I1{});
+  if constexpr (R > 2) { first_state(I2{}); first_state(I3{}); }
+  publish_lds(0);
+
+  Mail pre;                                        // the mail of a step's first row: in flight across the barrier
+  blank(pre);
+  {
+    unsigned pb0 = 0u;
+    asm volatile("" : "+s"(pb0));
+    if (!down) fetch(I0{}, pb0, pre); else fetch(ILast{}, pb0, pre);
+  }
 
   bool aborted = false;
   for (int s = 1; s <= a.nsteps; ++s) {
     int par = (s - 1) & 1;                         // parity of the state being pulled
     asm volatile("" : "+s"(par));                  // (keeps both parities' addresses from being hoisted into registers)
-    const uint32_t want = a.tag0 + (uint32_t)(s - 1);
+    const unsigned pb = (unsigned)par * BOX, pbn = BOX - pb;
+    const uint32_t want = a.tag0 + (uint32_t)(s - 1), tagn = want + 1u;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave's edge rows of state s-1 are in LDS
     if (*lds_abort != 0u) { aborted = true; break; }                  // (set before the barrier: every wave leaves here together)
+    stamp(s, 0);
     if (s > 1 && tid < 64) {                       // speed sum of step s-1
       float v = (lane < nw) ? red[par * 16 + lane] : 0.f;   // (written with parity (s-1)&1 at the end of step s-1)
       v = wave_sum(v);
       if (tid == 0) a.partials[(long)(s - 2) * nt + tile] = v;
     }
-    // ---- what enters the band: the row below (planes 2,5,6) and the row above (4,7,8)
-    float S[3], N[3];
-    bool ok = true;
-    const gu64* mybox = box(tile, par);
-    if (!first) {
-      const float* q = lds + ((par * 16 + (w - 1)) * 6 + 3) * 64 + lane;
-      S[0] = q[0]; S[1] = q[64]; S[2] = q[128];
-    }
-    if (!last) {
-      const float* q = lds + ((par * 16 + (w + 1)) * 6) * 64 + lane;
-      N[0] = q[0]; N[1] = q[64]; N[2] = q[128];
-    }
-    // ---- granules: south / north rows (edge waves), west / east columns (lanes 0 / 63), polled until all carry the tag
-    int rv = 0;                                    // the courier lanes' granule values
-    if (!DBG_NOLOAD) {
-      const long long t0 = wall_clock64();
-      for (;;) {
-        ok = true;
-        auto recv = [&](const gu64* g, float& dst) {
-          const unsigned long long x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = ok && ((uint32_t)(x >> 32) == want);
-          dst = __uint_as_float((uint32_t)x);
-        };
-        if (first) { recv(mybox + oS + lane, S[0]); recv(mybox + oS + 64 + lane, S[1]); recv(mybox + oS + 128 + lane, S[2]); }
-        if (last) { recv(mybox + oN + lane, N[0]); recv(mybox + oN + 64 + lane, N[1]); recv(mybox + oN + 128 + lane, N[2]); }
-        if (recv_on) { float v; recv((const gu64*)a.mail + (recv_off + (unsigned)(par * BOX)), v); rv = __float_as_int(v); }
-        if (__all(ok) || DBG_NOWAIT) break;
-        __builtin_amdgcn_s_sleep(1);
-        if (wall_clock64() - t0 > kResidentTimeoutTicks ||
-            __hip_atomic_load((gu32*)a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-          __hip_atomic_store((gu32*)a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          *lds_abort = 1u;
-          break;
+    const bool laststep = (s == a.nsteps);
+    float sp = 0.f;
+
+    // one row: wait for its mail, start the fetch of the next row's, update the row in place, send its granules.
+    //   lo = planes 2,5,6 of the row below, hi = planes 4,7,8 of the row above (old values); the band's first
+    //   row takes lo, its last row hi, from the neighbouring wave (LDS) or the neighbouring tile (mail)
+    auto send_stored = [&](auto rc) {             // the granules of a row that is finished: its populations are in f and own
+      constexpr int r = decltype(rc)::value;
+      float q[9];
+      q[0] = 0.f; q[1] = own[(r * 3 + 1) * 64]; q[3] = own[(r * 3 + 2) * 64];
+      q[2] = f[r][2]; q[4] = f[r][4]; q[5] = f[r][5]; q[6] = f[r][6]; q[7] = f[r][7]; q[8] = f[r][8];
+      send_row(rc, tagn, pbn, q);
+    };
+    auto do_row = [&](auto rc, auto next_c, auto prev_c, Mail& m, Mail& mnext, float (&lo)[3], float (&hi)[3]) {
+      constexpr int r = decltype(rc)::value, rnext = decltype(next_c)::value, rprev = decltype(prev_c)::value;
+      const int ord = down ? R - 1 - r : r;
+      stamp(s, 1 + 3 * ord);
+      await(rc, pb, want, m);
+      stamp(s, 2 + 3 * ord);
+      if constexpr (rprev >= 0) { if (!laststep) send_stored(prev_c); }   // (behind the wait: see the note on the stores above)
+      if (r == 0) {
+        if (first) { lo[0] = __uint_as_float(m.e.x); lo[1] = __uint_as_float(m.e.y); lo[2] = __uint_as_float(m.e.z); }
+        else {
+          const float* q = lds + ((par * nw + (w - 1)) * 6 + 3) * 64 + lane;
+          lo[0] = q[0]; lo[1] = q[64]; lo[2] = q[128];
         }
       }
-    }
-    // (a wave that gave up carries on with what it has; everybody leaves together behind the next barrier)
-    // ---- the step, in place, row by row upwards
-    const bool laststep = (s == a.nsteps);
-    // lane 0's population from the west tile sits in courier lane i (slot * R + row), lane 63's from the east tile in lane NM + i:
-    // the west tile's values belong to the EAST-column couriers' counterparts -- careful: couriers [0, NM) FETCH from this tile's
-    // WEST inbox (recv_off, side 0) and couriers [NM, 2 NM) from its EAST inbox
-    auto edge_w = [&](float v, int i) { return __int_as_float(rt_writelane<0>(__float_as_int(v), __builtin_amdgcn_readlane(rv, i))); };
-    auto edge_e = [&](float v, int i) { return __int_as_float(rt_writelane<63>(__float_as_int(v), __builtin_amdgcn_readlane(rv, NM + i))); };
-    float b2 = S[0], b5 = S[1], b6 = S[2];            // planes 2,5,6 of the row below the one being updated (old values)
-    float sp = 0.f;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
+      if (r == R - 1) {
+        if (last) {
+          const rt_u4 n = (R == 1) ? m.x : m.e;
+          hi[0] = __uint_as_float(n.x); hi[1] = __uint_as_float(n.y); hi[2] = __uint_as_float(n.z);
+        } else {
+          const float* q = lds + ((par * nw + (w + 1)) * 6) * 64 + lane;
+          hi[0] = q[0]; hi[1] = q[64]; hi[2] = q[128];
+        }
+      }
+      // couriers -> edge lanes: lane 0 / 63 holds row rho itself, the diagonal rows come one and two lanes over
+      const float m0 = __uint_as_float(m.g.x);
+      const float m1w = rt_row_shl<1>(m.g.y), m1e = rt_row_shr<1>(m.g.y);
+      const float m2w = rt_row_shl<2>(m.g.z), m2e = rt_row_shr<2>(m.g.z);
+      if constexpr (rnext >= 0) fetch(next_c, pb, mnext);   // the next row's mail, in flight behind this row's arithmetic
       float p[9];
-      const int ra = (r < R - 1) ? r + 1 : r;          // (compile-time after unrolling)
-      const float u4 = f[ra][4], u7 = f[ra][7], u8 = f[ra][8];
-      const float a4 = (r < R - 1) ? u4 : N[0], a7 = (r < R - 1) ? u7 : N[1], a8 = (r < R - 1) ? u8 : N[2];
-      p[0] = f[r][0];
-      p[1] = edge_w(rt_west(f[r][1]), 0 * R + r);
-      p[3] = edge_e(rt_east(f[r][3]), 0 * R + r);
-      p[2] = b2;
-      p[5] = edge_w(rt_west(b5), 1 * R + r);
-      p[6] = edge_e(rt_east(b6), 1 * R + r);
-      p[4] = a4;
-      p[7] = edge_e(rt_east(a7), 2 * R + r);
-      p[8] = edge_w(rt_west(a8), 2 * R + r);
-      b2 = f[r][2]; b5 = f[r][5]; b6 = f[r][6];       // saved before the row is overwritten
+      const float c0 = own[(r * 3 + 0) * 64], c1 = own[(r * 3 + 1) * 64], c3 = own[(r * 3 + 2) * 64];
+      p[0] = c0;
+      p[1] = rt_west(m0, c1);
+      p[3] = rt_east(m0, c3);
+      p[2] = lo[0];
+      p[5] = rt_west(m1w, lo[1]);
+      p[6] = rt_east(m1e, lo[2]);
+      p[4] = hi[0];
+      p[7] = rt_east(m2e, hi[1]);
+      p[8] = rt_west(m2w, hi[2]);
       sp += collide_cell<FAST>(p, blk[r], a.omega);
       if (gy0 + r == a.accel_row && !laststep) accelerate_cell(p, blk[r], a.a1, a.a2);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) f[r][k] = p[k];
+      f[r][2] = p[2]; f[r][4] = p[4]; f[r][5] = p[5]; f[r][6] = p[6]; f[r][7] = p[7]; f[r][8] = p[8];
+      own[(r * 3 + 0) * 64] = p[0]; own[(r * 3 + 1) * 64] = p[1]; own[(r * 3 + 2) * 64] = p[3];
       __builtin_amdgcn_sched_barrier(0);             // one row at a time: interleaving the rows costs more registers than the tile has to spare
-    }
-    if (!laststep) {                                   // mail first: it has the longest way to go
-      int parn = s & 1;
-      asm volatile("" : "+s"(parn));
-      publish(a.tag0 + (uint32_t)s, parn);
-    }
+      if constexpr (rnext < 0) { if (!laststep) send_row(rc, tagn, pbn, p); }   // the wave's last row of the step sends at once
+      stamp(s, 3 + 3 * ord);
+    };
+    // the wave's rows in order i = 0 .. R-1: row i going up, row R-1-i going down
+    auto sweep = [&](auto up_c) {
+      constexpr bool UP = decltype(up_c)::value;
+      float sv[3] = {0.f, 0.f, 0.f};                 // going up: old planes 2,5,6 of the row just overwritten; going down: 4,7,8
+      auto one = [&](auto ic, Mail& m, Mail& mnext) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int r = UP ? i : R - 1 - i;
+        // the SIMD issues by priority, then age: left alone it runs its oldest wave through all its rows before the
+        // next one starts, and what the row-by-row mail counts on -- neighbouring rows at most a row apart in TIME --
+        // is gone.  A wave's priority falls with every row it finishes: the four waves of a SIMD take turns, row by row.
+        __builtin_amdgcn_s_setprio(3 - i);
+        constexpr int rn = (i + 1 < R) ? (UP ? r + 1 : r - 1) : -1;
+        constexpr int rp = (i > 0) ? (UP ? r - 1 : r + 1) : -1;
+        float lo[3], hi[3], keep[3];
+        if constexpr (UP) {
+          constexpr int ra = (r < R - 1) ? r + 1 : r;
+          lo[0] = sv[0]; lo[1] = sv[1]; lo[2] = sv[2];
+          hi[0] = f[ra][4]; hi[1] = f[ra][7]; hi[2] = f[ra][8];       // (the band's last row: replaced in do_row)
+          keep[0] = f[r][2]; keep[1] = f[r][5]; keep[2] = f[r][6];
+        } else {
+          constexpr int rb = (r > 0) ? r - 1 : r;
+          hi[0] = sv[0]; hi[1] = sv[1]; hi[2] = sv[2];
+          lo[0] = f[rb][2]; lo[1] = f[rb][5]; lo[2] = f[rb][6];       // (the band's first row: replaced in do_row)
+          keep[0] = f[r][4]; keep[1] = f[r][7]; keep[2] = f[r][8];
+        }
+        do_row(std::integral_constant<int, r>{}, std::integral_constant<int, rn>{}, std::integral_constant<int, rp>{}, m, mnext, lo, hi);
+        sv[0] = keep[0]; sv[1] = keep[1]; sv[2] = keep[2];
+      };
+      Mail ma, mb;
+      if (DBG_NOLOAD) { blank(ma); blank(mb); }
+      one(I0{}, pre, ma);
+      if constexpr (R > 1) one(I1{}, ma, mb);
+      if constexpr (R > 2) { one(I2{}, mb, ma); one(I3{}, ma, mb); }
+      // the first row of the next step: its mail may be on its way already
+      if (!laststep) fetch(std::integral_constant<int, UP ? 0 : R - 1>{}, pbn, pre);
+    };
+    if (!down) sweep(std::true_type{}); else sweep(std::false_type{});
+    if (!laststep) publish_lds(s & 1);
+    stamp(s, 13);
     sp = wave_sum(sp);
     if (lane == 0) red[(s & 1) * 16 + w] = sp;
-    if (laststep) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const long o = (long)(gy0 + r) * a.pitch + gx;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) a.dst[k * a.plane + o] = f[r][k];
-      }
-    }
   }
   __syncthreads();
-  if (!aborted && *lds_abort == 0u && tid < 64) {
+  if (a.stats != nullptr && lane == 0) { atomicAdd(a.stats, (unsigned long long)nmiss); atomicAdd(a.stats + 1, (unsigned long long)nspin); }
+  if (aborted || *lds_abort != 0u) return;          // (the host repeats the run from the untouched source lattice)
+  {
+    int gyq = gy0, gxq = gx;                         // (addresses worked out again here: kept from the prologue they would live in scratch)
+    asm volatile("" : "+v"(gyq), "+v"(gxq));
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const long o = (long)(gyq + r) * a.pitch + gxq;
+      a.dst[o] = own[(r * 3 + 0) * 64]; a.dst[a.plane + o] = own[(r * 3 + 1) * 64]; a.dst[3 * a.plane + o] = own[(r * 3 + 2) * 64];
+#pragma unroll
+      for (int k = 2; k < 9; ++k)
+        if (k != 3) a.dst[k * a.plane + o] = f[r][k];
+    }
+  }
+  if (tid < 64) {
     float v = (lane < nw) ? red[(a.nsteps & 1) * 16 + lane] : 0.f;
     v = wave_sum(v);
     if (tid == 0) a.partials[(long)(a.nsteps - 1) * nt + tile] = v;

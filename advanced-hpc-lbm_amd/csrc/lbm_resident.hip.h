@@ -324,8 +324,11 @@ __global__ __launch_bounds__(1024) void lbm_resident(const ResidentArgs a) {
   }
 }
 
-// Per-step tile sums -> per-step lattice sums (double, fixed order): one wave per step.
-__global__ __launch_bounds__(kBlock) void lbm_fold_steps(const float* partials, int ntiles, int nsteps, double* sums) {
+// Per-step tile sums -> per-step lattice sums (double, fixed order): one wave per step.  `sums` and
+// `abort_out` may be pinned host memory; the abort word the tiles watched travels with the sums.
+__global__ __launch_bounds__(kBlock) void lbm_fold_steps(const float* partials, int ntiles, int nsteps, double* sums,
+                                                         const uint32_t* abort_word, uint32_t* abort_out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && abort_out != nullptr) *abort_out = *abort_word;
   const int step = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (step >= nsteps) return;
   const int lane = threadIdx.x & 63;
