@@ -27,7 +27,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblbm_mi355x.so")
+LIB_PATH = os.environ.get("LBM_MI355X_LIB") or os.path.join(_HERE, "liblbm_mi355x.so")   # (the override is for A/B timing of two builds)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lbm_mi355x.h")
 
 NSPEEDS = 9

@@ -60,7 +60,7 @@ struct RegTileArgs {
 };
 
 // LDS bytes of a block of nw waves with r rows per wave (see the kernel)
-__host__ __device__ constexpr int regtile_lds_bytes(int nw, int r) { return 4 * (nw * (2 * 6 * 64 + r * 3 * 64) + 2 * 16 + 16); }
+__host__ __device__ constexpr int regtile_lds_bytes(int nw, int r) { return 4 * (nw * (2 * 6 * 64 + (r == 4 ? r * 3 * 64 : 0)) + 2 * 16 + 16); }
 
 // bytes of one mailbox (one tile, one parity): Sin[64], Nin[64], Win[ty+2], Ein[ty+2] granules of 16 bytes
 __host__ __device__ constexpr int regtile_box(int ty) { return 16 * (2 * 64 + 2 * (ty + 2)); }
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
   // speed sums [parity][16]; abort word
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int nw_ = (int)(blockDim.x >> 6);
-  float* red = lds + nw_ * (2 * 6 * 64 + R * 3 * 64);
+  float* red = lds + nw_ * (2 * 6 * 64 + (R == 4 ? R * 3 * 64 : 0));
   uint32_t* lds_abort = reinterpret_cast<uint32_t*>(red + 32);
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -135,6 +135,8 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
   const int rho0 = w * R;                                   // tile row of this wave's first row
   const int gx = bx * 64 + lane, gy0 = by * TY + rho0;
   if (tid == 0) *lds_abort = 0u;
+  // planes 0, 1, 3 of row r: in LDS where the registers are short (four rows per wave), in f otherwise
+  constexpr bool OWN_LDS = (R == 4);
   float* own = lds + nw * (2 * 6 * 64) + w * (R * 3 * 64) + lane;   // own[(r * 3 + j) * 64]: plane {0,1,3}[j] of row r
 
   // east / west mail: lane 63 stores its row into the west inbox of the tile to the east, lane 0 into the east inbox of
@@ -221,15 +223,32 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
         a.stats[4 + ((w * 4 + (s - trace_s0)) * 16 + slot)] = __builtin_amdgcn_s_memtime();
     }
   };
+  // Wait until the mail of a row is there.  With several rows per wave the fetch that was started a row earlier
+  // usually has it, and if not it is fetched again.  A one-row wave (the small decks: the step IS the hand-off) polls
+  // with THREE loads in flight, a hundred cycles apart, each tested as it returns: the hand-off is seen one load
+  // latency (~2000 cycles through memory) after the granule became visible, not up to two.
   auto await = [&](auto rc, unsigned pb, uint32_t want, Mail& m) {
     if (DBG_NOLOAD || DBG_NOWAIT || arrived(rc, m, want)) return;
     const long long t0 = wall_clock64();
     ++nmiss;
     for (;;) {
-      __builtin_amdgcn_s_sleep(1);
-      ++nspin;
-      fetch(rc, pb, m);
-      if (arrived(rc, m, want)) return;
+      if constexpr (R == 1) {
+        Mail p1, p2;
+        fetch(rc, pb, m);
+        __builtin_amdgcn_s_sleep(2);
+        fetch(rc, pb, p1);
+        __builtin_amdgcn_s_sleep(2);
+        fetch(rc, pb, p2);
+        nspin += 3u;
+        if (arrived(rc, m, want)) return;
+        if (arrived(rc, p1, want)) { m = p1; return; }
+        if (arrived(rc, p2, want)) { m = p2; return; }
+      } else {
+        __builtin_amdgcn_s_sleep(1);
+        ++nspin;
+        fetch(rc, pb, m);
+        if (arrived(rc, m, want)) return;
+      }
       if (wall_clock64() - t0 > kResidentTimeoutTicks ||
           __hip_atomic_load((gu32*)a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
         __hip_atomic_store((gu32*)a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -255,7 +274,8 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
     blk[r] = a.blocked[o] != 0;
     if (gy0 + r == a.accel_row) accelerate_cell(q, blk[r], a.a1, a.a2);   // accelerate phase of the first step
     f[r][2] = q[2]; f[r][4] = q[4]; f[r][5] = q[5]; f[r][6] = q[6]; f[r][7] = q[7]; f[r][8] = q[8];
-    own[(r * 3 + 0) * 64] = q[0]; own[(r * 3 + 1) * 64] = q[1]; own[(r * 3 + 2) * 64] = q[3];
+    if constexpr (OWN_LDS) { own[(r * 3 + 0) * 64] = q[0]; own[(r * 3 + 1) * 64] = q[1]; own[(r * 3 + 2) * 64] = q[3]; }
+    else { f[r][0] = q[0]; f[r][1] = q[1]; f[r][3] = q[3]; }
     send_row(rc, a.tag0, 0u, q);
   };
   first_state(I0{});
@@ -268,7 +288,7 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
   {
     unsigned pb0 = 0u;
     asm volatile("" : "+s"(pb0));
-    if (!down) fetch(I0{}, pb0, pre); else fetch(ILast{}, pb0, pre);
+    if constexpr (R > 1) { if (!down) fetch(I0{}, pb0, pre); else fetch(ILast{}, pb0, pre); }
   }
 
   bool aborted = false;
@@ -294,7 +314,8 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
     auto send_stored = [&](auto rc) {             // the granules of a row that is finished: its populations are in f and own
       constexpr int r = decltype(rc)::value;
       float q[9];
-      q[0] = 0.f; q[1] = own[(r * 3 + 1) * 64]; q[3] = own[(r * 3 + 2) * 64];
+      q[0] = 0.f;
+      if constexpr (OWN_LDS) { q[1] = own[(r * 3 + 1) * 64]; q[3] = own[(r * 3 + 2) * 64]; } else { q[1] = f[r][1]; q[3] = f[r][3]; }
       q[2] = f[r][2]; q[4] = f[r][4]; q[5] = f[r][5]; q[6] = f[r][6]; q[7] = f[r][7]; q[8] = f[r][8];
       send_row(rc, tagn, pbn, q);
     };
@@ -327,7 +348,9 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
       const float m2w = rt_row_shl<2>(m.g.z), m2e = rt_row_shr<2>(m.g.z);
       if constexpr (rnext >= 0) fetch(next_c, pb, mnext);   // the next row's mail, in flight behind this row's arithmetic
       float p[9];
-      const float c0 = own[(r * 3 + 0) * 64], c1 = own[(r * 3 + 1) * 64], c3 = own[(r * 3 + 2) * 64];
+      float c0, c1, c3;
+      if constexpr (OWN_LDS) { c0 = own[(r * 3 + 0) * 64]; c1 = own[(r * 3 + 1) * 64]; c3 = own[(r * 3 + 2) * 64]; }
+      else { c0 = f[r][0]; c1 = f[r][1]; c3 = f[r][3]; }
       p[0] = c0;
       p[1] = rt_west(m0, c1);
       p[3] = rt_east(m0, c3);
@@ -340,7 +363,8 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
       sp += collide_cell<FAST>(p, blk[r], a.omega);
       if (gy0 + r == a.accel_row && !laststep) accelerate_cell(p, blk[r], a.a1, a.a2);
       f[r][2] = p[2]; f[r][4] = p[4]; f[r][5] = p[5]; f[r][6] = p[6]; f[r][7] = p[7]; f[r][8] = p[8];
-      own[(r * 3 + 0) * 64] = p[0]; own[(r * 3 + 1) * 64] = p[1]; own[(r * 3 + 2) * 64] = p[3];
+      if constexpr (OWN_LDS) { own[(r * 3 + 0) * 64] = p[0]; own[(r * 3 + 1) * 64] = p[1]; own[(r * 3 + 2) * 64] = p[3]; }
+      else { f[r][0] = p[0]; f[r][1] = p[1]; f[r][3] = p[3]; }
       __builtin_amdgcn_sched_barrier(0);             // one row at a time: interleaving the rows costs more registers than the tile has to spare
       if constexpr (rnext < 0) { if (!laststep) send_row(rc, tagn, pbn, p); }   // the wave's last row of the step sends at once
       stamp(s, 3 + 3 * ord);
@@ -379,7 +403,8 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
       if constexpr (R > 1) one(I1{}, ma, mb);
       if constexpr (R > 2) { one(I2{}, mb, ma); one(I3{}, ma, mb); }
       // the first row of the next step: its mail may be on its way already
-      if (!laststep) fetch(std::integral_constant<int, UP ? 0 : R - 1>{}, pbn, pre);
+      // (a one-row wave has only just sent: what it would fetch cannot be there yet, it polls behind the barrier)
+      if constexpr (R > 1) { if (!laststep) fetch(std::integral_constant<int, UP ? 0 : R - 1>{}, pbn, pre); }
     };
     if (!down) sweep(std::true_type{}); else sweep(std::false_type{});
     if (!laststep) publish_lds(s & 1);
@@ -396,7 +421,8 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const long o = (long)(gyq + r) * a.pitch + gxq;
-      a.dst[o] = own[(r * 3 + 0) * 64]; a.dst[a.plane + o] = own[(r * 3 + 1) * 64]; a.dst[3 * a.plane + o] = own[(r * 3 + 2) * 64];
+      if constexpr (OWN_LDS) { a.dst[o] = own[(r * 3 + 0) * 64]; a.dst[a.plane + o] = own[(r * 3 + 1) * 64]; a.dst[3 * a.plane + o] = own[(r * 3 + 2) * 64]; }
+      else { a.dst[o] = f[r][0]; a.dst[a.plane + o] = f[r][1]; a.dst[3 * a.plane + o] = f[r][3]; }
 #pragma unroll
       for (int k = 2; k < 9; ++k)
         if (k != 3) a.dst[k * a.plane + o] = f[r][k];
