@@ -14,7 +14,7 @@
 
 #include "../advanced-hpc-lbm_amd/csrc/lbm_exact_math.hip.h"
 
-using lbm::recip_short; using lbm::root_short;
+using lbm::recip_short; using lbm::root_short; using lbm::recip_exact; using lbm::root_exact;
 
 __device__ __forceinline__ bool same(float a, float b) {
   const uint32_t x = __float_as_uint(a), y = __float_as_uint(b);
@@ -22,7 +22,8 @@ __device__ __forceinline__ bool same(float a, float b) {
   return (nx && ny) || x == y;
 }
 
-// which = 0: recip_short vs 1/x; 1: root_short vs sqrtf.  hist[biased exponent of x][sign] counts mismatches.
+// which = 0: recip_short vs 1/x; 1: root_short vs sqrtf; 2, 3: the guarded recip_exact / root_exact the kernels call (must
+// never differ).  hist[biased exponent of x][sign] counts mismatches.
 template <int WHICH>
 __global__ void sweep_all(unsigned long long* hist, unsigned long long* first_bad) {
   const uint64_t n = 1ull << 32;
@@ -30,7 +31,9 @@ __global__ void sweep_all(unsigned long long* hist, unsigned long long* first_ba
     const float x = __uint_as_float((uint32_t)i);
     float got, want;
     if (WHICH == 0) { got = recip_short(x); want = 1.0f / x; }
-    else { got = root_short(x); want = sqrtf(x); }
+    else if (WHICH == 1) { got = root_short(x); want = sqrtf(x); }
+    else if (WHICH == 2) { got = recip_exact(x); want = 1.0f / x; }
+    else { got = root_exact(x); want = sqrtf(x); }
     if (!same(got, want)) {
       const uint32_t e = ((uint32_t)i >> 23) & 0xffu, s = (uint32_t)i >> 31;
       atomicAdd(&hist[e * 2 + s], 1ull);
@@ -43,11 +46,14 @@ int main() {
   unsigned long long *hist, *bad;
   CK(hipMalloc(&hist, 512 * 8)); CK(hipMalloc(&bad, 8));
   int rc = 0;
-  for (int which = 0; which < 2; ++which) {
+  const char* names[4] = {"recip_short", "root_short", "recip_exact", "root_exact"};
+  for (int which = 0; which < 4; ++which) {
     CK(hipMemset(hist, 0, 512 * 8));
     CK(hipMemset(bad, 0xff, 8));
     if (which == 0) hipLaunchKernelGGL(sweep_all<0>, dim3(4096), dim3(256), 0, 0, hist, bad);
-    else hipLaunchKernelGGL(sweep_all<1>, dim3(4096), dim3(256), 0, 0, hist, bad);
+    if (which == 1) hipLaunchKernelGGL(sweep_all<1>, dim3(4096), dim3(256), 0, 0, hist, bad);
+    if (which == 2) hipLaunchKernelGGL(sweep_all<2>, dim3(4096), dim3(256), 0, 0, hist, bad);
+    if (which == 3) hipLaunchKernelGGL(sweep_all<3>, dim3(4096), dim3(256), 0, 0, hist, bad);
     CK(hipDeviceSynchronize());
     unsigned long long h[512], b;
     CK(hipMemcpy(h, hist, sizeof h, hipMemcpyDeviceToHost));
@@ -57,19 +63,30 @@ int main() {
       for (int s = 0; s < 2; ++s) {
         total += h[e * 2 + s];
         // inputs the guard of the short sequence lets through: see lbm_exact_math.hip.h
-        const bool in_guard = which == 0 ? (e >= lbm::kRecipExpLo && e <= lbm::kRecipExpHi) : (s == 0 && e >= lbm::kRootExpLo && e <= lbm::kRootExpHi);
+        const bool in_guard = which >= 2 ? true
+                            : which == 0 ? (e >= lbm::kRecipExpLo && e <= lbm::kRecipExpHi) : (s == 0 && e >= lbm::kRootExpLo && e <= lbm::kRootExpHi);
         if (in_guard) guarded += h[e * 2 + s];
       }
-    printf("%s: %llu of 2^32 inputs differ from the IEEE result, %llu of them inside the guard\n",
-           which == 0 ? "recip_short" : "root_short", total, guarded);
+    printf("%s: %llu of 2^32 inputs differ from the IEEE result, %llu of them %s\n",
+           names[which], total, guarded, which >= 2 ? "count (guarded function: none may)" : "inside the guard");
     if (total) {
-      printf("  first differing input: 0x%08llx; by biased exponent (sign +/-):", b);
-      for (int e = 0; e < 256; ++e)
-        if (h[e * 2] || h[e * 2 + 1]) printf(" %d:%llu/%llu", e, h[e * 2], h[e * 2 + 1]);
-      printf("\n");
+      // biased exponents (of x > 0, then of x < 0) with at least one differing input, as ranges
+      printf("  first differing input: 0x%08llx\n", b);
+      for (int sgn = 0; sgn < 2; ++sgn) {
+        printf("  x %s 0, exponents with differing inputs:", sgn ? "<" : ">");
+        for (int e = 0; e < 256; ++e) {
+          if (!h[e * 2 + sgn]) continue;
+          int e1 = e;
+          while (e1 + 1 < 256 && h[(e1 + 1) * 2 + sgn]) ++e1;
+          if (e1 > e) printf(" %d-%d", e, e1); else printf(" %d", e);
+          e = e1;
+        }
+        printf("\n");
+      }
     }
     if (guarded) rc = 1;
   }
-  printf(rc ? "FAILED: a guarded input gives a different result\n" : "OK: inside their guards both short sequences are correctly rounded for every input\n");
+  printf(rc ? "FAILED: a guarded input gives a different result\n"
+            : "OK: inside their guards both short sequences are correctly rounded for every input, and the guarded functions for all 2^32\n");
   return rc;
 }
