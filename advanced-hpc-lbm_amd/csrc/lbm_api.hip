@@ -677,6 +677,7 @@ int ensure_sums(Slab& s, int nsteps) {
 bool plan_resident(lbm_ctx* c);   // resident engines, below
 bool plan_regtile(lbm_ctx* c);
 bool march_slabs_setup(lbm_ctx* c);   // marching kernel across slabs, below
+template <int K> int wave_blocks_per_cu();   // occupancy of lbm_wave<K>, below
 bool p2p_march_pays(const lbm_ctx* c);
 int march_rows_for(const lbm_ctx* c, int ny_rows);
 
@@ -728,6 +729,18 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
       else if (!use_wave_kernel(c)) { if (march_efficiency(c, march_pick_rows(c)) < 0.65) c->time_block = 2; }
       else if ((long)c->p.nx * c->p.ny < (3L << 20)) c->time_block = 2;   // lbm_wave needs a few thousand waves: from about 2048^2
       else c->time_block = 6;
+      // Eight steps per pass in registers (lbm_wave<8>, 10.5 B per update, bound by its arithmetic) overtakes lbm_march
+      // (19.4 B, bound by HBM) once the lattice gives every wave slot of the chip three chunks of 128 rows to work
+      // through: measured in one call at 8192^2 304 against 284 GLUPS (4096^2: 262 against 286, 2048^2: 217 against 231).
+      if (c->time_block == 4 && c->march_kernel < 0 && !getenv("LBM_MARCH_KERNEL") && c->p.nx >= 64 && c->p.ny >= 128 &&
+          (double)c->p.ny * c->slabs[0].pitch * 4.0 < 4.0e9) {
+        const long waves = (long)cdiv(c->p.nx, 64 - 2 * 8) * cdiv(c->p.ny, 128);
+        const long slots = (long)std::max(c->ncu, 1) * std::max(wave_blocks_per_cu<8>(), 1) * (lbm::kWaveBlock / 64);
+        if (waves >= 3 * slots) {
+          c->time_block = 8; c->march_kernel = 1;
+          if (c->wave_rows <= 0) c->wave_rows = 128;
+        }
+      }
     }
   }
   return LBM_OK;
@@ -1353,7 +1366,7 @@ void wave_plan(lbm_ctx* c) {
   if (bpc < 1) bpc = 4;
   c->wave_capacity = std::max(c->ncu, 1) * bpc * (lbm::kWaveBlock / 64);
   if (c->wave_rows > 0) return;
-  c->wave_rows = std::min(c->p.ny, K >= 8 ? 96 : K >= 6 ? 64 : 32);
+  c->wave_rows = std::min(c->p.ny, K >= 8 ? 128 : K >= 6 ? 64 : 32);
 }
 
 // One lbm_wave launch: steps tt .. tt+K-1 of the lone slab, launch index li.

@@ -113,7 +113,7 @@ template <bool FAST> __device__ __forceinline__ float root(float x) {
 // what the optimiser happens to fuse in a given instantiation: all kernels built from it
 // (1, 2 or 4 cells per thread, one or two steps per pass, any slab decomposition) produce
 // bit-identical lattices.
-template <bool FAST>
+template <bool FAST, bool SPARSE = false>
 __device__ __forceinline__ float collide_cell(float (&p)[9], bool is_blocked, float omega) {
 #pragma clang fp contract(off)
   const float w0 = 4.f / 9.f, w1 = 1.f / 9.f, w2 = 1.f / 36.f;
@@ -141,15 +141,22 @@ __device__ __forceinline__ float collide_cell(float (&p)[9], bool is_blocked, fl
   float t[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) t[k] = __builtin_fmaf(omega, d[k] - p[k], p[k]);   // p + omega (d - p)
-  // post-collision speed from the values about to be stored
-  float rho2 = t[0];
+  // The cell's speed for the step's average (d2q9-bgk.c:1783-1811 takes it from the post-collision populations).
+  // BGK relaxation conserves the cell's mass and momentum -- sum t_k = rho and sum t_k c_k = rho u, the equilibrium
+  // having been built from exactly these -- so the post-collision velocity IS (ux, uy), up to the rounding of the
+  // float sums (a few 1e-9 absolute per cell, random in sign: parts in 1e8 of a step's average, against the 1 % of
+  // the reference's checker and the 2e-6 the tests hold it to).  Recomputing it from t[] cost 24 of the ~110
+  // instructions of this function, in kernels that are bound by exactly those (lbm_regtile, lbm_wave).
+  const float speed = root<FAST>(usq);
+  // blocked cell: mirrored pulled values instead, no contribution.  SPARSE: most wavefronts hold no blocked cell at all
+  // (0.5 % of the shipped 1024^2 deck is blocked) and skip the ten selects behind one wave-uniform branch.
+  if constexpr (SPARSE) {
+    if (__builtin_expect(__any(is_blocked) == 0, 1)) {
 #pragma unroll
-  for (int k = 1; k < 9; ++k) rho2 += t[k];
-  const float inv2 = recip<FAST>(rho2);
-  const float vx = (t[1] + t[5] + t[8] - (t[3] + t[6] + t[7])) * inv2;
-  const float vy = (t[2] + t[5] + t[6] - (t[4] + t[7] + t[8])) * inv2;
-  const float speed = root<FAST>(__builtin_fmaf(vx, vx, vy * vy));
-  // blocked cell: mirrored pulled values instead, no contribution
+      for (int k = 0; k < 9; ++k) p[k] = t[k];
+      return speed;
+    }
+  }
   const float b1 = p[3], b2 = p[4], b3 = p[1], b4 = p[2], b5 = p[7], b6 = p[8], b7 = p[5], b8 = p[6];
   p[0] = is_blocked ? p[0] : t[0];
   p[1] = is_blocked ? b1 : t[1];

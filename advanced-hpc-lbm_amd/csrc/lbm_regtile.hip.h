@@ -360,7 +360,7 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
       p[4] = hi[0];
       p[7] = rt_east(m2e, hi[1]);
       p[8] = rt_west(m2w, hi[2]);
-      sp += collide_cell<FAST>(p, blk[r], a.omega);
+      sp += collide_cell<FAST, true>(p, blk[r], a.omega);
       if (gy0 + r == a.accel_row && !laststep) accelerate_cell(p, blk[r], a.a1, a.a2);
       f[r][2] = p[2]; f[r][4] = p[4]; f[r][5] = p[5]; f[r][6] = p[6]; f[r][7] = p[7]; f[r][8] = p[8];
       if constexpr (OWN_LDS) { own[(r * 3 + 0) * 64] = p[0]; own[(r * 3 + 1) * 64] = p[1]; own[(r * 3 + 2) * 64] = p[3]; }

@@ -37,7 +37,7 @@ def test_bench_line_single_gpu(gpu):
     assert ro["equiv_72B_frac"] > ro["frac"] and abs(ratio * ro["min_bytes_per_lattice_update"] / 72.0 - 1.0) < 0.05
     assert ro["traffic"] is None or ro["traffic"] > 0
     big = d["also"]["8192x8192"]["roofline"]
-    assert big["kernel"] == "lbm_march<4>" and big["steps_per_launch"] == 4 and 0.0 < big["frac"] <= 1.0
+    assert big["kernel"] == "lbm_wave<8>" and big["steps_per_launch"] == 8 and 0.0 < big["frac"] <= 1.0   # (the default from 3 chunks per wave slot)
     assert d["gpu_ms_per_step"] <= d["ms_per_step"] and d["results_bitexact"] is None
     cb = d["cpu_baseline"]
     assert cb["unit"] == "MLUPS" and cb["cores"] == 1 and cb["kind"] in ("reference", "port") and cb["value"] > 1
