@@ -20,6 +20,7 @@
 // wave's loads with another's arithmetic (lbm_march, the LDS form of the same idea, spends a third of
 // its time in the barrier that keeps its sixteen waves in step).
 #pragma once
+#include <type_traits>
 #include "lbm_kernels.hip.h"
 
 namespace lbm {
@@ -133,7 +134,10 @@ void lbm_wave(const WaveArgs a) {
     unsigned mreg = 0u;                          // bit l = obstacle flag of the row level l works on
     float nxt[9]; int nblk;
     load_row(nxt, nblk);
-    for (int j = 0; j < niter; ++j) {
+    // One iteration.  STEADY: past the 2K fill iterations of the chunk every level has its history, the "is this level
+    // running yet" tests are gone and with them the register copies their merge points force (a quarter of the loop).
+    auto iteration = [&](auto steady_c, int j) {
+      constexpr bool STEADY = decltype(steady_c)::value;
       float cur[9];
 #pragma unroll
       for (int k = 0; k < 9; ++k) cur[k] = nxt[k];
@@ -144,7 +148,7 @@ void lbm_wave(const WaveArgs a) {
         float p[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) p[k] = cur[k];
-        if (j >= 2 * l) {
+        if (STEADY || j >= 2 * l) {
           // pull (d2q9-bgk.c:2139-2147): row above = cur, same row = Bp, row below = C2 of interface l-1
           p[0] = Bp[l - 1][0];
           p[1] = from_west(Bp[l - 1][1]);
@@ -161,7 +165,7 @@ void lbm_wave(const WaveArgs a) {
           if ((jl == jacc || jl == jacc2) && (l < K || a.accel_out != 0)) accelerate_cell(p, blk, a.a1, a.a2);
           sum[l - 1] += (out_ok && jl >= K && jl < K + hy) ? sp : 0.f;
         }
-        if (j >= 2 * (l - 1)) {                  // the producer's row of this iteration becomes history for the next two
+        if (STEADY || j >= 2 * (l - 1)) {        // the producer's row of this iteration becomes history for the next two
           C2[l - 1][0] = C1[l - 1][0]; C2[l - 1][1] = C1[l - 1][1]; C2[l - 1][2] = C1[l - 1][2];
           C1[l - 1][0] = cur[2]; C1[l - 1][1] = cur[5]; C1[l - 1][2] = cur[6];
           Bp[l - 1][0] = cur[0]; Bp[l - 1][1] = cur[1]; Bp[l - 1][2] = cur[3];
@@ -169,7 +173,7 @@ void lbm_wave(const WaveArgs a) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) cur[k] = p[k];
       }
-      if (j >= 2 * K) {                          // level K's row S0 + j - K = Y0 + (j - 2K)
+      if (STEADY || j >= 2 * K) {                // level K's row S0 + j - K = Y0 + (j - 2K)
         if (out_ok) {
 #pragma unroll
           for (int k = 0; k < 9; ++k)
@@ -177,7 +181,10 @@ void lbm_wave(const WaveArgs a) {
         }
         st_off += ld_step;
       }
-    }
+    };
+    int j = 0;
+    for (; j < 2 * K && j < niter; ++j) iteration(std::false_type{}, j);
+    for (; j < niter; ++j) iteration(std::true_type{}, j);
     }
   }
 
