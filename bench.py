@@ -258,7 +258,7 @@ def measure(name, world, rank, local_rank, steps, warmup):
         min_bytes = 72.0 / steps
     achieved = min_bytes * lups_per_launch / launch_s / 1e9
     equiv72 = BYTES_PER_LUP * lups_per_launch / launch_s / 1e9
-    traffic = lookup_traffic(name, world, kernel)
+    traffic = lookup_traffic(name, world, kernel, steps)
     return {
         "wall_us": {"timed_region": round(dt * 1e6, 1), "lbm_run_call": round(t_run * 1e6, 1),
                     "inside_library": round(lib_ms * 1e3, 1), "gpu_events": round(gpu_ms * 1e3, 1)},
@@ -267,7 +267,7 @@ def measure(name, world, rank, local_rank, steps, warmup):
         "gpu_ms_per_step": gpu_ms / steps,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": kernel, "steps_per_launch": tb,
+                     "kernel": kernel, "steps_per_launch": tb, "what_binds_it": BINDS.get(kernel.split("<")[0], ""),
                      # `achieved` prices a lattice update at the bytes THIS kernel's blocking must move
                      # (kernel_of), so frac <= 1 by construction; the same rate priced at the one-step
                      # kernel's 72 B per update is reported separately and may exceed 1
@@ -284,14 +284,31 @@ def measure(name, world, rank, local_rank, steps, warmup):
     }
 
 
-def lookup_traffic(name, world, kernel):
+# what the committed profiles say limits each kernel: the HBM fraction alone does not tell it
+BINDS = {
+    "lbm_regtile": "the lattice stays in registers and HBM is crossed twice per run, so the HBM fraction is ~0 by design; a step is "
+                   "four tile-to-tile hand-offs of ~2000 cycles (sc1 store, sc1 load) overlapped with ~1000 cycles of arithmetic "
+                   "per row (profiles/r02_sq_counters.json: waves wait 49 % of their cycles)",
+    "lbm_wave": "its arithmetic (151 lane-instructions per update at K = 8 with fill rows and undelivered lanes): HBM traffic is "
+                "10 B per update",
+    "lbm_march": "HBM: 19.3 B per update measured, ~0.64 of peak; the 18-stream access pattern alone tops out at ~5.9 TB/s nominal",
+    "lbm_sweep2": "HBM: 38.9 B per update",
+    "lbm_sweep": "HBM: 72 B per update",
+}
+
+
+def lookup_traffic(name, world, kernel, steps=0):
     """HBM bytes per launch of `kernel` on workload `name` from the committed rocprofv3 PMC passes
     (profiles/hbm_traffic.json, written by tools/summarize_profile.py), or None."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if world != 1 or not os.path.exists(path):
         return None
     try:
-        return json.load(open(path)).get(name, {}).get(kernel.split("<")[0], {}).get("hbm_bytes_per_launch")
+        key = kernel.replace("<", "").replace(">", "") if kernel.startswith("lbm_wave") else kernel.split("<")[0]
+        e = json.load(open(path)).get(name, {}).get(key, {})
+        if key == "lbm_regtile" and e:          # one launch per run: the lattice once, plus the tiles' mail per step
+            return e["hbm_fixed_bytes_per_launch"] + steps * e["hbm_bytes_per_step"]
+        return e.get("hbm_bytes_per_launch")
     except Exception:
         return None
 
