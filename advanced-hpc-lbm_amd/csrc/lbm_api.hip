@@ -1669,6 +1669,7 @@ int run_regtile(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
   a.ty = t.ty; a.ntx = t.ntx; a.nty = t.nty;
   a.nsteps = nsteps; a.tag0 = c->rtag;
   a.mail = c->tmail; a.mail_bytes = (unsigned)mail_bytes; a.partials = c->rpartials; a.abort_word = c->rabort;
+  a.fault = getenv("LBM_REGTILE_FAULT") ? 1 : 0;   // (tests: a tile that never starts)
   a.stats = nullptr;
   static const bool want_stats = getenv("LBM_REGTILE_STATS") != nullptr;   // development: missed polls per run, and a trace
   static unsigned long long* stats_buf = nullptr;

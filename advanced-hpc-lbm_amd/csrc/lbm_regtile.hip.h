@@ -56,6 +56,7 @@ struct RegTileArgs {
   unsigned mail_bytes;
   float* partials;             // [nsteps][ntiles]
   uint32_t* abort_word;
+  int fault;                   // test hook: tile 0 never starts (its neighbours time out, the host falls back)
   unsigned long long* stats;   // development: [0] += waits that found their mail missing, [1] += extra fetches (or nullptr)
 };
 
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
   using I3 = std::integral_constant<int, 3 % R>;
   using ILast = std::integral_constant<int, R - 1>;
 
+  if (a.fault != 0 && tile == 0) return;
   // ---- state 0: loaded, and sent row by row like every other state
   auto first_state = [&](auto rc) {
     constexpr int r = decltype(rc)::value;

@@ -13,6 +13,7 @@ Bit-exact where the arithmetic is the same: repeatability, split runs, slab deco
 x-translations (all are the same per-cell float operations in a different launch geometry)."""
 import os
 import subprocess
+import time
 
 import numpy as np
 import pytest
@@ -1076,3 +1077,30 @@ def test_short_reciprocal_and_square_root_are_correctly_rounded_for_every_float(
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK: inside their guards" in r.stdout
     assert "recip_exact: 0 of 2^32" in r.stdout and "root_exact: 0 of 2^32" in r.stdout
+
+
+def test_register_tile_kernel_that_cannot_finish_falls_back_to_the_streaming_kernels(gpu, monkeypatch):
+    """A tile of lbm_regtile that never runs (here: told not to; in the field: a CU it did not get) leaves its
+    neighbours waiting; every wait is bounded (1 s) and watches the abort word, the kernel leaves the source lattice
+    untouched, and lbm_run repeats the steps with the streaming kernels: same lattice, engine_last says so."""
+    L = gpu
+    rng = np.random.default_rng(77)
+    p = L.Param(128, 128, 40, 10, 0.1, 0.01, 1.85)
+    ob = (rng.random((128, 128)) < 0.05).astype(np.int32)
+    with L.Lattice(p, ob) as a:
+        a.set_option("time_block", 1)
+        av_a = a.run(9)
+        st_a = a.read_state()
+    monkeypatch.setenv("LBM_REGTILE_FAULT", "1")
+    with L.Lattice(p, ob) as b:
+        assert b.info("engine_next") == 3
+        t0 = time.perf_counter()
+        av_b = b.run(9)
+        waited = time.perf_counter() - t0
+        assert b.info("engine_last") == 1 and 0.5 < waited < 10.0
+        st_b = b.read_state()
+        monkeypatch.delenv("LBM_REGTILE_FAULT")
+        b.run(3)
+        assert b.info("engine_last") == 1          # (it stays with the streaming kernels on this context)
+    assert np.array_equal(st_a.view(np.uint32), st_b.view(np.uint32))
+    assert np.allclose(av_a, av_b, rtol=2e-6, atol=0)
