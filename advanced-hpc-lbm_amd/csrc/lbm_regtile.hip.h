@@ -22,13 +22,16 @@
 //                             instruction per row -- a memory instruction costs its issue slot whether one
 //                             lane is active or sixty-four -- through a buffer descriptor (32-bit offsets);
 //                             nothing in the loop waits for a store (no vmcnt wait, no __syncthreads).
-// A hand-off through L2 takes about a microsecond (MI355X_MICROARCH.md, handoff-1to1), a fifth of a step of a
-// full tile, and the first form of this loop -- mail sent after the last row, polled before the first --
-// waited for all of it.  Now the mail travels ROW BY ROW: a row's granules leave as soon as the row is done,
-// and a row's mail is fetched while the row before it is being computed.  What makes that hide the hand-off
-// is the order of the rows: even waves sweep their rows upwards, odd waves downwards (when the tile has an
-// even number of waves), so that rows which are neighbours in space -- across waves and across tiles -- are
-// at most one row apart in time, and every granule is R - 2 row-times old when it is needed.
+// A hand-off through memory takes about 2000 cycles (a write-through store, then an sc1 load that misses L2 by
+// design), a fifth of a step of a full tile, and the first form of this loop -- mail sent after the last row, polled
+// before the first -- waited for all of it.  Now the mail travels ROW BY ROW: a row's mail is fetched while the row
+// before it is computed, and a row's granules leave right after the wait for the next row's mail (not before it: a
+// store behind a branch would make that wait a wait for the store's acknowledgement, see the note at ew_voff).  What
+// makes that hide most of the hand-off is the order of the rows: even waves sweep their rows upwards, odd waves
+// downwards (when the tile has an even number of waves), so that rows which are neighbours in space -- across waves
+// and across tiles -- are at most one row apart in time and every granule is two row-times old when it is asked for;
+// and s_setprio falling with every finished row, so that the four waves of a SIMD take turns row by row instead of
+// oldest first.  One-row waves (small tiles) have nothing to pipeline: they poll behind the barrier, three loads in flight.
 // The update is in place, with three saved registers (the old planes 2,5,6 -- going down: 4,7,8 -- of the
 // row just overwritten).  Mailbox of a tile, per parity: Sin / Nin [64 columns] (from the tile below /
 // above), Win / Ein [TY + 2 rows] (rows -1 .. TY: the two extra rows are the diagonal tiles' corner rows).
