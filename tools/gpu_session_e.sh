@@ -10,7 +10,7 @@ echo "== pytest" && timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/
 [ $rc -eq 0 ] || exit 1
 echo "== bench driver-style" && timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err && cat $O/bench_driver.json &&
 echo "== bench default" && timeout -k 10 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err && cat $O/bench_default.json &&
-echo "== kernel trace" && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python3 bench.py --cpu-sample-steps 0 > $O/trace.log 2>&1 &&
+echo "== kernel trace" && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python3 bench.py --warmup 0 --cpu-sample-steps 0 > $O/trace.log 2>&1 &&
 echo "== pmc fetch 8192" && timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmcF8 --output-format csv -- python3 bench.py --workload 8192x8192 --steps 40 --warmup 4 --also '' --cpu-sample-steps 0 > $O/pmcF8.log 2>&1 &&
 echo "== pmc write 8192" && timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmcW8 --output-format csv -- python3 bench.py --workload 8192x8192 --steps 40 --warmup 4 --also '' --cpu-sample-steps 0 > $O/pmcW8.log 2>&1 &&
 echo "== pmc fetch 1024" && timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmcF1 --output-format csv -- python3 bench.py --steps 400 --warmup 20 --also '' --cpu-sample-steps 0 > $O/pmcF1.log 2>&1 &&
