@@ -366,7 +366,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="1024x1024")
     ap.add_argument("--also", default="8192x8192", help="second workload reported under 'also' ('' to skip)")
-    ap.add_argument("--also-steps", type=int, default=300)
+    ap.add_argument("--also-steps", type=int, default=320)
     ap.add_argument("--cpu-sample-steps", type=int, default=1000, help="0 = skip the CPU baseline")
     ap.add_argument("--rehearse-multi", action="store_true",
                     help="one GPU only: run the N>1 code path (RCCL communicator, halo self-check, peer-to-peer "
