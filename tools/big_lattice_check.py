@@ -16,3 +16,10 @@ print("translation invariance bit-exact:", ok, "av close:", np.allclose(av1, av2
 with L.Lattice(p, ob) as lat:
     lat.set_option("time_block", 1); av3 = lat.run(6); f3 = lat.final_state()
 print("two-step == one-step bit-exact:", np.array_equal(f1.view(np.uint32), f3.view(np.uint32)), flush=True)
+# the default from ~8192^2 up: eight steps per pass in registers (lbm_wave<8>); 19 steps = two passes + a pair + one
+with L.Lattice(p, ob) as lat:
+    av4 = lat.run(19); g4, _ = lat.last_run_ms(); tb = int(lat.info("time_block_active")); s4 = lat.read_state()
+with L.Lattice(p, ob) as lat:
+    lat.set_option("time_block", 1); av5 = lat.run(19); s5 = lat.read_state()
+print(f"default ({tb} steps per pass) == one-step bit-exact over 19 steps:", np.array_equal(s4.view(np.uint32), s5.view(np.uint32)),
+      "av close:", np.allclose(av4, av5, rtol=2e-6), "MLUPS", n * n * 19 / (g4 * 1e-3) / 1e6, flush=True)
