@@ -679,6 +679,7 @@ bool plan_regtile(lbm_ctx* c);
 bool march_slabs_setup(lbm_ctx* c);   // marching kernel across slabs, below
 template <int K> int wave_blocks_per_cu();   // occupancy of lbm_wave<K>, below
 bool p2p_march_pays(const lbm_ctx* c);
+bool slab_wave_pays(const lbm_ctx* c, int rows);
 int march_rows_for(const lbm_ctx* c, int ny_rows);
 
 int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
@@ -710,6 +711,7 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
       // peer-to-peer halos (one process or one process per GPU): lbm_march where the smallest slab fills the chip
       // (a function of the lattice and the number of slabs only: every rank decides alike)
       if (c->p.nx % 4 == 0 && c->p.nx >= lbm::MarchCfg<kMarchK>::W && c->p.ny / c->nranks >= 4 * kMarchK && p2p_march_pays(c)) c->time_block = 4;
+      if (c->time_block == 4 && c->march_kernel != 0 && !getenv("LBM_MARCH_KERNEL") && slab_wave_pays(c, c->p.ny / c->nranks)) c->time_block = 8;
     } else
     if (!getenv("LBM_TIME_BLOCK") && c->time_block == 2 && exchanging) {
       // slabs of one process: lbm_march with the neighbours' rows read in place, where every slab fills the chip
@@ -722,6 +724,11 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
         if ((double)s.nyl * ns / ((double)rounds * std::max(c->ncu, 1) * (h + 3 * (kMarchK - 1))) < 0.65) ok = false;
       }
       if (!ok) { c->time_block = 2; c->march_slabs = -1; }
+      else if (c->march_kernel != 0 && !getenv("LBM_MARCH_KERNEL")) {
+        bool w8 = true;
+        for (auto& s : c->slabs) w8 = w8 && slab_wave_pays(c, s.nyl);
+        if (w8) c->time_block = 8;
+      }
     } else
     if (!getenv("LBM_TIME_BLOCK") && c->time_block == 2) {
       c->time_block = 4;
@@ -1257,10 +1264,11 @@ bool march_slabs_setup(lbm_ctx* c) {
   if (c->march_slabs >= 0) return c->march_slabs == 1;
   c->march_slabs = 0;
   if (c->rank_mode || c->exchange == 0 || c->exchange == LBM_EXCHANGE_RCCL) return false;
-  if (c->p.nx % 4 != 0 || c->p.nx < lbm::MarchCfg<kMarchK>::W) return false;
+  const int K = (c->time_block == 8) ? 8 : kMarchK;
+  if (K == 8 ? c->p.nx < 64 : (c->p.nx % 4 != 0 || c->p.nx < lbm::MarchCfg<kMarchK>::W)) return false;
   const int ns = (int)c->slabs.size();
   for (auto& s : c->slabs)
-    if (s.nyl < 4 * kMarchK || (double)s.nyl * s.pitch * 4.0 >= 4.0e9) return false;
+    if (s.nyl < 4 * K || (double)s.nyl * s.pitch * 4.0 >= 4.0e9) return false;
   for (int i = 0; i < ns; ++i)
     for (int d : {(i + ns - 1) % ns, (i + 1) % ns}) {
       const int a = c->slabs[i].dev, b = c->slabs[d].dev;
@@ -1275,7 +1283,14 @@ bool march_slabs_setup(lbm_ctx* c) {
   c->march_slabs = 1;
   return true;
 }
-inline bool march_slabs_on(lbm_ctx* c) { return c->time_block == kMarchK && c->march_kernel != 1 && march_slabs_setup(c); }
+// Steps per marching pass of a context whose slabs trade rows: 8 = lbm_wave<8>, 4 = lbm_march, 0 = no marching.
+inline int slab_K(const lbm_ctx* c) {
+  if (c->exchange == 0) return 0;
+  if (c->time_block == 8) return (c->p.nx >= 64) ? 8 : 0;
+  if (c->time_block == kMarchK) return (c->p.nx % 4 == 0 && c->p.nx >= lbm::MarchCfg<kMarchK>::W) ? kMarchK : 0;
+  return 0;
+}
+inline bool march_slabs_on(lbm_ctx* c) { return slab_K(c) != 0 && march_slabs_setup(c); }
 
 int march_rows_for(const lbm_ctx* c, int ny_rows) {
   const int ns = cdiv(c->p.nx, lbm::MarchCfg<kMarchK>::WOUT), ncu = std::max(c->ncu, 1);
@@ -1289,14 +1304,91 @@ int march_rows_for(const lbm_ctx* c, int ny_rows) {
   }
   return best_h;
 }
+// Rows per chunk of lbm_wave<8> on a slab of ny_rows rows, and the share of the chip's wave-slot time that is useful
+// work with it: a chunk costs 2K fill iterations, and waves that do not fill the last round leave slots idle.
+int wave_slots(const lbm_ctx* c) { return std::max(c->ncu, 1) * std::max(wave_blocks_per_cu<8>(), 1) * (lbm::kWaveBlock / 64); }
+double slab_wave_efficiency(const lbm_ctx* c, int ny_rows, int h) {
+  const long waves = (long)cdiv(c->p.nx, 64 - 16) * cdiv(ny_rows, h), slots = wave_slots(c);
+  const double rounds = waves <= 2 * slots ? (double)((waves + slots - 1) / slots) : (double)waves / slots;   // (many rounds overlap)
+  return (double)waves / (rounds * slots) * h / (h + 16.0);
+}
+int slab_wave_rows(const lbm_ctx* c, int ny_rows) {
+  if (c->wave_rows > 0) return std::min(c->wave_rows, ny_rows);
+  int best_h = std::min(ny_rows, 128);
+  double best = -1.0;
+  for (int h = std::min(ny_rows, 32); h <= std::min(ny_rows, 128); h += 8) {     // (beyond 128 rows the chunks get slower: measured)
+    const double e = slab_wave_efficiency(c, ny_rows, h);
+    if (e > best + 1e-9) { best = e; best_h = h; }
+  }
+  return best_h;
+}
+// partial-sum slots (blocks) of one marching launch on a slab
 inline int march_slab_blocks(const lbm_ctx* c, const Slab& s) {
+  if (slab_K(c) == 8) return cdiv((long)cdiv(c->p.nx, 64 - 16) * cdiv(s.nyl, slab_wave_rows(c, s.nyl)), lbm::kWaveBlock / 64);
   return cdiv(c->p.nx, lbm::MarchCfg<kMarchK>::WOUT) * cdiv(s.nyl, march_rows_for(c, s.nyl));
+}
+
+// The neighbours of a slab as a marching launch sees them.
+struct SlabNb { const float* src_s; const float* src_n; long plane_s, plane_n; int ny_s, ny_n; const uint8_t* blk_s; const uint8_t* blk_n; };
+
+// One marching launch on one slab: steps tt .. tt+K-1, partial sums into buffer q (folding the previous launch's).
+int launch_slab_pass(lbm_ctx* c, Slab& s, const SlabNb& nbr, int K, int q, int tt, bool accel_out, bool fold_prev) {
+  const float a1 = c->p.density * c->p.accel / 9.f, a2 = c->p.density * c->p.accel / 36.f;
+  const int nb = march_slab_blocks(c, s), qp = q ^ 1;
+  if ((long)K * nb > s.partial_cap) return fail(LBM_EINVAL, "marching kernel: %d blocks exceed the partial-sum buffer", nb);
+  // the lattice's accelerate row (ny-2) in this slab's row numbers, and its periodic images: one of them may fall
+  // into the K rows this slab recomputes on a neighbour's behalf
+  const int ar = (c->p.ny - 2) - s.row0;
+  const int flavour = (int)(c->variant & (lbm::kFastMath | lbm::kNtStore));
+  if (K == 8) {
+    lbm::WaveArgs a;
+    a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
+    a.plane = s.plane; a.pitch = s.pitch; a.nx = c->p.nx; a.ny = s.nyl;
+    a.blocked = s.blocked; a.omega = c->p.omega;
+    a.accel_row = lbm::kNoRow; a.accel_out = accel_out ? 1 : 0; a.a1 = a1; a.a2 = a2;
+    a.H = slab_wave_rows(c, s.nyl);
+    a.nwc = cdiv(c->p.nx, 64 - 16); a.nchunks = cdiv(s.nyl, a.H);
+    a.partials = s.partials[q];
+    a.prev = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
+    if (fold_prev) { a.prev = s.partials[qp]; a.prev_count = nb; a.prev_sum = s.sums + (tt - K); }
+    a.src_s = nbr.src_s; a.src_n = nbr.src_n; a.plane_s = nbr.plane_s; a.plane_n = nbr.plane_n;
+    a.ny_s = nbr.ny_s; a.ny_n = nbr.ny_n; a.blocked_s = nbr.blk_s; a.blocked_n = nbr.blk_n;
+    a.acc_rows[0] = ar; a.acc_rows[1] = ar - c->p.ny; a.acc_rows[2] = ar + c->p.ny;
+    switch (flavour) {
+      case 0: hipLaunchKernelGGL((lbm::lbm_wave<8, 0, true>), dim3(nb), dim3(lbm::kWaveBlock), 0, s.sc, a); break;
+      case 1: hipLaunchKernelGGL((lbm::lbm_wave<8, 1, true>), dim3(nb), dim3(lbm::kWaveBlock), 0, s.sc, a); break;
+      case 2: hipLaunchKernelGGL((lbm::lbm_wave<8, 2, true>), dim3(nb), dim3(lbm::kWaveBlock), 0, s.sc, a); break;
+      default: hipLaunchKernelGGL((lbm::lbm_wave<8, 3, true>), dim3(nb), dim3(lbm::kWaveBlock), 0, s.sc, a); break;
+    }
+  } else {
+    using Cfg = lbm::MarchCfg<kMarchK>;
+    lbm::MarchArgs a;
+    a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
+    a.plane = s.plane; a.pitch = s.pitch; a.nx = c->p.nx; a.ny = s.nyl;
+    a.blocked = s.blocked; a.omega = c->p.omega;
+    a.accel_row = lbm::kNoRow; a.accel_out = accel_out ? 1 : 0; a.a1 = a1; a.a2 = a2;
+    a.H = march_rows_for(c, s.nyl);
+    a.nstrips = cdiv(c->p.nx, Cfg::WOUT); a.nchunks = cdiv(s.nyl, a.H);
+    a.partials = s.partials[q];
+    a.prev = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
+    if (fold_prev) { a.prev = s.partials[qp]; a.prev_count = nb; a.prev_sum = s.sums + (tt - K); }
+    a.src_s = nbr.src_s; a.src_n = nbr.src_n; a.plane_s = nbr.plane_s; a.plane_n = nbr.plane_n;
+    a.ny_s = nbr.ny_s; a.ny_n = nbr.ny_n; a.blocked_s = nbr.blk_s; a.blocked_n = nbr.blk_n;
+    a.acc_rows[0] = ar; a.acc_rows[1] = ar - c->p.ny; a.acc_rows[2] = ar + c->p.ny;
+    switch (flavour) {
+      case 0: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 0, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
+      case 1: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 1, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
+      case 2: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 2, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
+      default: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 3, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
+    }
+  }
+  HIPC(hipGetLastError());
+  return LBM_OK;
 }
 
 // One marching launch group over all slabs: steps tt .. tt+K-1, launch index li.
 int launch_march_slabs(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev) {
-  using Cfg = lbm::MarchCfg<kMarchK>;
-  const int ns = (int)c->slabs.size(), q = li & 1, qp = q ^ 1;
+  const int ns = (int)c->slabs.size(), q = li & 1, qp = q ^ 1, K = slab_K(c);
   for (int i = 0; i < ns; ++i) {
     Slab& s = c->slabs[i];
     Slab& so = c->slabs[(i + ns - 1) % ns];
@@ -1304,33 +1396,9 @@ int launch_march_slabs(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_pre
     HIPC(hipSetDevice(s.dev));
     HIPC(hipStreamWaitEvent(s.sc, so.ev_march[qp], 0));
     HIPC(hipStreamWaitEvent(s.sc, no.ev_march[qp], 0));
-    lbm::MarchArgs a;
-    a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
-    a.plane = s.plane; a.pitch = s.pitch; a.nx = c->p.nx; a.ny = s.nyl;
-    a.blocked = s.blocked; a.omega = c->p.omega;
-    a.accel_row = lbm::kNoRow; a.accel_out = accel_out ? 1 : 0;
-    a.a1 = c->p.density * c->p.accel / 9.f; a.a2 = c->p.density * c->p.accel / 36.f;
-    a.H = march_rows_for(c, s.nyl);
-    a.nstrips = cdiv(c->p.nx, Cfg::WOUT); a.nchunks = cdiv(s.nyl, a.H);
-    const int nb = a.nstrips * a.nchunks;
-    if ((long)kMarchK * nb > s.partial_cap) return fail(LBM_EINVAL, "marching kernel: %d blocks exceed the partial-sum buffer", nb);
-    a.partials = s.partials[q];
-    a.prev = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
-    if (fold_prev) { a.prev = s.partials[qp]; a.prev_count = nb; a.prev_sum = s.sums + (tt - kMarchK); }
-    a.src_s = so.lat[c->cur]; a.src_n = no.lat[c->cur];
-    a.plane_s = so.plane; a.plane_n = no.plane; a.ny_s = so.nyl; a.ny_n = no.nyl;
-    a.blocked_s = so.blocked; a.blocked_n = no.blocked;
-    // the lattice's accelerate row (ny-2) in this slab's row numbers, and its periodic images: one of them may fall
-    // into the K rows this slab recomputes on a neighbour's behalf
-    const int ar = (c->p.ny - 2) - s.row0;
-    a.acc_rows[0] = ar; a.acc_rows[1] = ar - c->p.ny; a.acc_rows[2] = ar + c->p.ny;
-    switch ((int)(c->variant & (lbm::kFastMath | lbm::kNtStore))) {
-      case 0: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 0, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
-      case 1: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 1, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
-      case 2: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 2, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
-      default: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 3, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
-    }
-    HIPC(hipGetLastError());
+    const SlabNb nbr{so.lat[c->cur], no.lat[c->cur], so.plane, no.plane, so.nyl, no.nyl, so.blocked, no.blocked};
+    const int rc = launch_slab_pass(c, s, nbr, K, q, tt, accel_out, fold_prev);
+    if (rc) return rc;
     HIPC(hipEventRecord(s.ev_march[q], s.sc));
   }
   c->cur ^= 1;
@@ -1769,10 +1837,10 @@ inline float* p2p_remote_n(const Slab& s, uint32_t seq) { return (float*)(s.peer
 // chip.  The decision uses the lattice, the number of slabs and the options only -- every rank must come to the same
 // answer, the two protocols do not mix.
 bool p2p_march_on(const lbm_ctx* c) {
-  if (c->time_block != kMarchK || c->march_kernel == 1 || c->exchange != LBM_EXCHANGE_P2P) return false;
-  if (c->p.nx % 4 != 0 || c->p.nx < lbm::MarchCfg<kMarchK>::W) return false;
+  const int K = slab_K(c);
+  if (K == 0 || c->exchange != LBM_EXCHANGE_P2P) return false;
   const int rows = c->p.ny / c->nranks;                     // the smallest slab
-  if (rows < 4 * kMarchK || (double)(rows + 1) * c->slabs[0].pitch * 4.0 >= 4.0e9) return false;
+  if (rows < 4 * K || (double)(rows + 1) * c->slabs[0].pitch * 4.0 >= 4.0e9) return false;
   for (auto& s : c->slabs) if (!s.nb_lat[0][0] || !s.nb_lat[1][0]) return false;   // (connect failed: an error everywhere)
   return true;
 }
@@ -1780,6 +1848,15 @@ bool p2p_march_pays(const lbm_ctx* c) {                      // same estimate as
   const int rows = c->p.ny / c->nranks, h = march_rows_for(c, rows), ns = cdiv(c->p.nx, lbm::MarchCfg<kMarchK>::WOUT), ncu = std::max(c->ncu, 1);
   const long blocks = (long)ns * cdiv(rows, h), rounds = (blocks + ncu - 1) / ncu;
   return (double)rows * ns / ((double)rounds * ncu * (h + 3 * (kMarchK - 1))) >= 0.65;
+}
+// lbm_wave<8> instead of lbm_march on slabs of `rows` rows?  When its waves fill at least most of one round of the
+// chip's wave slots.  Measured on one GPU (tools/strong_scaling_proxy.py, us per step, lbm_wave<8> against lbm_march):
+// 8192 x 4096 126 / 135, 8192 x 2048 69.3 / 70.3, 8192 x 1024 38.7 / 39.4 -- a little ahead everywhere, with half as
+// many launches (and flag hand-offs over xGMI) per step; 1024-wide slabs (22 wave columns) are far too narrow: 12.4 / 5.4.
+bool slab_wave_pays(const lbm_ctx* c, int rows) {
+  if (c->p.nx < 64 || rows < 32 || c->march_kernel == 0) return false;
+  const int h = slab_wave_rows(c, rows);
+  return (double)cdiv(c->p.nx, 64 - 16) * cdiv(rows, h) >= 0.85 * wave_slots(c);
 }
 
 // The step loop with peer-to-peer halos: one stream per slab, no events, no host-side exchange.
@@ -1825,8 +1902,8 @@ int run_p2p(lbm_ctx* c, int nsteps, float* av_vels) {
   // ---- groups of K steps with lbm_march: the K ghost rows either side are read straight out of the neighbours'
   // lattices.  Launch group seq of a slab starts once both neighbours have raised seq-1 ("my launch seq-1 is over":
   // their rows are final, and they no longer read the lattice this launch overwrites) and raises seq when it is over.
-  if (p2p_march_on(c) && nsteps >= kMarchK) {
-    using Cfg = lbm::MarchCfg<kMarchK>;
+  if (p2p_march_on(c) && nsteps >= slab_K(c)) {
+    const int K = slab_K(c);
     auto raise = [&](Slab& s, uint32_t q) -> int {
       const size_t f = 4 * s.halo_bytes;
       hipLaunchKernelGGL(lbm::lbm_p2p_raise, dim3(1), dim3(64), 0, s.sc, (uint32_t*)(s.peer_s + f + 256), (uint32_t*)(s.peer_n + f), q);
@@ -1839,38 +1916,16 @@ int run_p2p(lbm_ctx* c, int nsteps, float* av_vels) {
       if ((rc = push(s, nullptr, seq, false))) return rc;   // (the neighbours are through with the previous run)
       if ((rc = raise(s, seq))) return rc;
     }
-    const int ngroups = nsteps / kMarchK;
-    for (int g = 0; g < ngroups; ++g, ++li, tt += kMarchK) {
+    const int ngroups = nsteps / K;
+    for (int g = 0; g < ngroups; ++g, ++li, tt += K) {
       seq = ++c->seq;
-      const int q = li & 1, qp = q ^ 1;
+      const int q = li & 1;
       for (auto& s : c->slabs) {
         HIPC(hipSetDevice(s.dev));
         if ((rc = push(s, nullptr, seq, false))) return rc;   // wait for both neighbours' seq-1
-        lbm::MarchArgs a;
-        a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
-        a.plane = s.plane; a.pitch = s.pitch; a.nx = nx; a.ny = s.nyl;
-        a.blocked = s.blocked; a.omega = c->p.omega;
-        a.accel_row = lbm::kNoRow; a.accel_out = (tt + kMarchK < nsteps) ? 1 : 0;
-        a.a1 = a1; a.a2 = a2;
-        a.H = march_rows_for(c, s.nyl);
-        a.nstrips = cdiv(nx, Cfg::WOUT); a.nchunks = cdiv(s.nyl, a.H);
-        const int nb = a.nstrips * a.nchunks;
-        if ((long)kMarchK * nb > s.partial_cap) return fail(LBM_EINVAL, "marching kernel: %d blocks exceed the partial-sum buffer", nb);
-        a.partials = s.partials[q];
-        a.prev = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
-        if (g > 0) { a.prev = s.partials[qp]; a.prev_count = nb; a.prev_sum = s.sums + (tt - kMarchK); }
-        a.src_s = s.nb_lat[0][c->cur]; a.src_n = s.nb_lat[1][c->cur];
-        a.plane_s = s.nb_plane[0]; a.plane_n = s.nb_plane[1]; a.ny_s = s.nb_nyl[0]; a.ny_n = s.nb_nyl[1];
-        a.blocked_s = s.nb_blocked[0]; a.blocked_n = s.nb_blocked[1];
-        const int ar = (c->p.ny - 2) - s.row0;
-        a.acc_rows[0] = ar; a.acc_rows[1] = ar - c->p.ny; a.acc_rows[2] = ar + c->p.ny;
-        switch ((int)(c->variant & (lbm::kFastMath | lbm::kNtStore))) {
-          case 0: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 0, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
-          case 1: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 1, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
-          case 2: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 2, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
-          default: hipLaunchKernelGGL((lbm::lbm_march<kMarchK, 3, true>), dim3(nb), dim3(kMarchK * 256), 0, s.sc, a); break;
-        }
-        HIPC(hipGetLastError());
+        const SlabNb nbr{s.nb_lat[0][c->cur], s.nb_lat[1][c->cur], s.nb_plane[0], s.nb_plane[1], s.nb_nyl[0], s.nb_nyl[1],
+                         s.nb_blocked[0], s.nb_blocked[1]};
+        if ((rc = launch_slab_pass(c, s, nbr, K, q, tt, tt + K < nsteps, g > 0))) return rc;
         if ((rc = raise(s, seq))) return rc;
       }
       c->cur ^= 1;
@@ -1878,8 +1933,8 @@ int run_p2p(lbm_ctx* c, int nsteps, float* av_vels) {
     for (auto& s : c->slabs) {
       HIPC(hipSetDevice(s.dev));
       const int nb = march_slab_blocks(c, s);
-      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(kMarchK), dim3(lbm::kBlock), 0, s.sc, s.partials[(li - 1) & 1], nb,
-                         s.sums + (tt - kMarchK), nb);
+      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(K), dim3(lbm::kBlock), 0, s.sc, s.partials[(li - 1) & 1], nb,
+                         s.sums + (tt - K), nb);
       HIPC(hipGetLastError());
     }
   }
@@ -2004,7 +2059,7 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
     if ((rc = ensure_sums(s, nsteps))) return rc;
 
   // ---- prologue: accelerate phase of the first step
-  const bool slabs_march = ex && march_slabs_on(c) && nsteps >= kMarchK;
+  const bool slabs_march = ex && march_slabs_on(c) && nsteps >= slab_K(c);
   for (auto& s : c->slabs) {
     HIPC(hipSetDevice(s.dev));
     if (s.accel_row >= 0) {
@@ -2044,14 +2099,14 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
   // selects the halo / partial-sum buffers.
   int li = 0, tt = 0;
   if (slabs_march) {                                   // groups of K steps, row-marching, every slab of this process
-    const int ngroups = nsteps / kMarchK;
-    for (int g = 0; g < ngroups; ++g, ++li, tt += kMarchK)
-      if ((rc = launch_march_slabs(c, li, tt, tt + kMarchK < nsteps, g > 0))) return rc;
+    const int K = slab_K(c), ngroups = nsteps / K;
+    for (int g = 0; g < ngroups; ++g, ++li, tt += K)
+      if ((rc = launch_march_slabs(c, li, tt, tt + K < nsteps, g > 0))) return rc;
     for (auto& s : c->slabs) {
       HIPC(hipSetDevice(s.dev));
       const int nb = march_slab_blocks(c, s);
-      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(kMarchK), dim3(lbm::kBlock), 0, s.sc, s.partials[(li - 1) & 1], nb,
-                         s.sums + (tt - kMarchK), nb);
+      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(K), dim3(lbm::kBlock), 0, s.sc, s.partials[(li - 1) & 1], nb,
+                         s.sums + (tt - K), nb);
       HIPC(hipGetLastError());
     }
     if (tt < nsteps) {
@@ -2264,7 +2319,7 @@ extern "C" int lbm_set_option(lbm_ctx* c, const char* key, long value) {
   }
   if (!strcmp(key, "time_block")) {
     if (value != 1 && value != 2 && value != 4 && value != 6 && value != 8) return fail(LBM_EINVAL, "time_block must be 1, 2, 4, 6 or 8");
-    if (value != c->time_block) { c->wave_rows = 0; c->wave_capacity = 0; }
+    if (value != c->time_block) { c->wave_rows = 0; c->wave_capacity = 0; if (c->march_slabs == 0) c->march_slabs = -1; }   // (what the slabs can march depends on K)
     c->time_block = (int)value;
     c->engine = 1;
     return LBM_OK;
@@ -2313,7 +2368,7 @@ extern "C" int lbm_get_info(const lbm_ctx* c, const char* key, double* value) {
                  ? c->time_block : t2_eligible(c) ? 2 : 1;
     return LBM_OK;
   }
-  if (!strcmp(key, "march_kernel")) { *value = (march_eligible(c) && use_wave_kernel(c)) ? 1 : 0; return LBM_OK; }
+  if (!strcmp(key, "march_kernel")) { *value = ((march_eligible(c) && use_wave_kernel(c)) || (c->exchange != 0 && slab_K(c) == 8)) ? 1 : 0; return LBM_OK; }
   if (!strcmp(key, "wave_rows")) { *value = c->wave_rows; return LBM_OK; }
   if (!strcmp(key, "wave_capacity")) { *value = c->wave_capacity; return LBM_OK; }
   if (!strcmp(key, "march_rows")) { *value = c->march_rows > 0 ? c->march_rows : march_pick_rows(c); return LBM_OK; }

@@ -41,6 +41,14 @@ struct WaveArgs {
   const float* prev;           // the previous launch's partials, folded by block 0 (or nullptr)
   int prev_count;              // its block count
   double* prev_sum;            // K doubles
+  // ---- a slab with neighbours (SLAB kernels; the same protocol as lbm_march's, lbm_march.hip.h): `ny` rows are this
+  // slab's, the K rows below row 0 and above row ny-1 are read straight from the neighbours' lattices; the host orders
+  // the launches (launch n+1 of a slab starts after launch n of both neighbours).
+  const float* src_s; const float* src_n;
+  long plane_s, plane_n;
+  int ny_s, ny_n;
+  const uint8_t* blocked_s; const uint8_t* blocked_n;
+  int acc_rows[3];             // this slab's row indices of the lattice's accelerate row and of its periodic images
 };
 
 constexpr int kWaveBlock = 256;   // four independent waves per block (they only meet for the final sums)
@@ -58,7 +66,7 @@ __device__ __forceinline__ float from_east(float v) {   // wave_shl:1
 // updates per iteration, so it is other waves, not instruction-level parallelism, that keep a SIMD busy
 constexpr int wave_min_occupancy(int K) { return K <= 6 ? 4 : 3; }
 
-template <int K, int MODE>
+template <int K, int MODE, bool SLAB = false>
 __global__ __launch_bounds__(kWaveBlock) __attribute__((amdgpu_waves_per_eu(wave_min_occupancy(K))))
 void lbm_wave(const WaveArgs a) {
   constexpr bool FAST = (MODE & kFastMath) != 0, NTS = (MODE & kNtStore) != 0, NTL = (MODE & kNtLoad) != 0;
@@ -112,15 +120,32 @@ void lbm_wave(const WaveArgs a) {
     // iterations (minus the level) in which a level's row is the accelerate row: the chunk plus its fill
     // rows may pass it twice
     int jacc = (a.accel_row - S0) % a.ny; jacc += (jacc < 0) ? a.ny : 0;
-    const int jacc2 = jacc + a.ny;
+    int jacc2 = jacc + a.ny, jacc3 = -1;
+    if constexpr (SLAB) {                       // nothing wraps in y: the three images of the accelerate row, as they are
+      jacc = a.acc_rows[0] - S0; jacc2 = a.acc_rows[1] - S0; jacc3 = a.acc_rows[2] - S0;
+    }
+    int srow = S0;                              // SLAB: the source row about to be loaded, in this slab's numbering
 
     auto load_row = [&](float (&f)[9], int& blk) {
+      if constexpr (SLAB) {
+        // rows below 0 live at the top of the southern neighbour's lattice, rows from ny up at the bottom of the northern one's
+        const float* base = a.src; long pl = a.plane; const uint8_t* bl = a.blocked; int r = srow;
+        if (srow < 0) { base = a.src_s; pl = a.plane_s; bl = a.blocked_s; r = srow + a.ny_s; }
+        else if (srow >= a.ny) { base = a.src_n; pl = a.plane_n; bl = a.blocked_n; r = srow - a.ny; }
+        const unsigned off = ((unsigned)r * (unsigned)a.pitch + (unsigned)gx) * 4u;
 #pragma unroll
-      for (int k = 0; k < 9; ++k)
-        f[k] = ldg<NTL>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.src + k * a.plane) + ld_off));
-      blk = a.blocked[ld_off >> 2];
-      ++gy;
-      if (gy == a.ny) { gy = 0; ld_off -= ld_back; } else { ld_off += ld_step; }
+        for (int k = 0; k < 9; ++k)
+          f[k] = ldg<NTL>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + k * pl) + off));
+        blk = bl[off >> 2];
+        ++srow;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+          f[k] = ldg<NTL>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.src + k * a.plane) + ld_off));
+        blk = a.blocked[ld_off >> 2];
+        ++gy;
+        if (gy == a.ny) { gy = 0; ld_off -= ld_back; } else { ld_off += ld_step; }
+      }
     };
 
     {
@@ -162,7 +187,7 @@ void lbm_wave(const WaveArgs a) {
           const bool blk = ((mreg >> l) & 1u) != 0u;
           const float sp = collide_cell<FAST>(p, blk, a.omega);
           const int jl = j - l;
-          if ((jl == jacc || jl == jacc2) && (l < K || a.accel_out != 0)) accelerate_cell(p, blk, a.a1, a.a2);
+          if ((jl == jacc || jl == jacc2 || (SLAB && jl == jacc3)) && (l < K || a.accel_out != 0)) accelerate_cell(p, blk, a.a1, a.a2);
           sum[l - 1] += (out_ok && jl >= K && jl < K + hy) ? sp : 0.f;
         }
         if (STEADY || j >= 2 * (l - 1)) {        // the producer's row of this iteration becomes history for the next two

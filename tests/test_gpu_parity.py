@@ -981,11 +981,12 @@ def test_default_engine_by_lattice(gpu):
 
 
 @pytest.mark.parametrize("exchange", ["copy", "p2p"])
-@pytest.mark.parametrize("nx,ny,nslabs,steps", [(256, 64, 2, [4]), (256, 96, 3, [8, 5]), (480, 200, 4, [13]), (1024, 1024, 8, [16, 3])])
-def test_marching_kernel_across_slabs_of_one_process(gpu, exchange, nx, ny, nslabs, steps):
-    """lbm_march on row slabs: the K ghost rows either side are read straight out of the neighbouring slab's lattice
-    (no halo buffers), launches ordered by events (copy contexts) or by in-kernel flags (peer-to-peer contexts);
-    remainders of a run fall back to the halo-trading kernels.  Bit-identical to the undivided lattice."""
+@pytest.mark.parametrize("K,nx,ny,nslabs,steps", [(4, 256, 64, 2, [4]), (4, 256, 96, 3, [8, 5]), (4, 480, 200, 4, [13]), (4, 1024, 1024, 8, [16, 3]),
+                                                  (8, 256, 64, 2, [8]), (8, 100, 96, 3, [16, 11]), (8, 480, 200, 4, [29]), (8, 1024, 1024, 8, [16, 3])])
+def test_marching_kernel_across_slabs_of_one_process(gpu, exchange, K, nx, ny, nslabs, steps):
+    """lbm_march (K = 4) and lbm_wave<8> (K = 8) on row slabs: the K ghost rows either side are read straight out of the
+    neighbouring slab's lattice (no halo buffers), launches ordered by events (copy contexts) or by in-kernel flags
+    (peer-to-peer contexts); remainders of a run fall back to the halo-trading kernels.  Bit-identical to the undivided lattice."""
     L = gpu
     p, ob, cells = _random_case(L, nx, ny, 9)
     with L.Lattice(p, ob, cells) as a:
@@ -994,15 +995,15 @@ def test_marching_kernel_across_slabs_of_one_process(gpu, exchange, nx, ny, nsla
         st_a = a.read_state()
     ex = L.EXCHANGE_COPY if exchange == "copy" else L.EXCHANGE_P2P
     with L.Lattice(p, ob, cells, nslabs=nslabs, devices=[0] * nslabs, exchange=ex) as b:
-        b.set_option("time_block", 4)
-        assert b.info("time_block_active") == 4
+        b.set_option("time_block", K)
+        assert b.info("time_block_active") == K and b.info("march_kernel") == (1 if K == 8 else 0)
         av_b = np.concatenate([b.run(n) for n in steps])
         st_b = b.read_state()
     assert np.array_equal(st_a.view(np.uint32), st_b.view(np.uint32))
     assert np.allclose(av_a, av_b, rtol=2e-6, atol=0)
 
 
-def _p2p_march_rank_worker(rank, nranks, shape, nsteps_list, conn, outdir):
+def _p2p_march_rank_worker(rank, nranks, shape, nsteps_list, conn, outdir, K=4):
     import sys
     for p_ in (ROOT, os.path.join(ROOT, "oracle")):
         if p_ not in sys.path:
@@ -1010,10 +1011,10 @@ def _p2p_march_rank_worker(rank, nranks, shape, nsteps_list, conn, outdir):
     import advanced_hpc_lbm_amd as L
     p, ob, cells = _random_case(L, shape[0], shape[1], 13)
     lat = L.Lattice(p, ob, cells, rank=rank, nranks=nranks, device=0, unique_id=None, exchange=L.EXCHANGE_P2P)
-    lat.set_option("time_block", 4)
+    lat.set_option("time_block", K)
     conn.send(lat.p2p_handle())
     lat.p2p_connect(conn.recv())
-    assert lat.info("time_block_active") == 4
+    assert lat.info("time_block_active") == K
     av = np.concatenate([lat.run(n) for n in nsteps_list])
     np.save(os.path.join(outdir, f"av_{rank}.npy"), av)
     np.save(os.path.join(outdir, f"state_{rank}.npy"), lat.read_state())
@@ -1022,14 +1023,16 @@ def _p2p_march_rank_worker(rank, nranks, shape, nsteps_list, conn, outdir):
     lat.close()
 
 
-@pytest.mark.parametrize("nranks", [2, 3])
-def test_marching_kernel_between_processes(gpu, tmp_path, nranks):
+@pytest.mark.parametrize("nranks,K", [(2, 4), (3, 4), (2, 8), (3, 8)])
+def test_marching_kernel_between_processes(gpu, tmp_path, nranks, K):
     """One process per slab (here sharing one GPU): each rank's lbm_march launches read the neighbouring ranks' rows out
     of THEIR lattices, mapped through hipIpc handles that travel in the halo blocks; launches ordered by flags raised
     by a one-thread kernel behind each launch.  Bit-identical to the undivided lattice; av_vels contributions add up."""
     import multiprocessing as mp
     L = gpu
-    shape, splits = (256, 96), [8, 5]
+    shape, splits = ((256, 96), [8, 5]) if K == 4 else ((192, 96 * nranks // 2), [16, 11])   # (K = 8: 48 / 48 / 32.. rows per rank)
+    if K == 8 and nranks == 3:
+        shape = (192, 144)
     p, ob, cells = _random_case(L, shape[0], shape[1], 13)
     with L.Lattice(p, ob, cells) as lat:
         lat.set_option("time_block", 1)
@@ -1037,7 +1040,7 @@ def test_marching_kernel_between_processes(gpu, tmp_path, nranks):
         st1 = lat.read_state()
     ctx = mp.get_context("spawn")
     pipes = [ctx.Pipe() for _ in range(nranks)]
-    procs = [ctx.Process(target=_p2p_march_rank_worker, args=(r, nranks, shape, splits, pipes[r][1], str(tmp_path)))
+    procs = [ctx.Process(target=_p2p_march_rank_worker, args=(r, nranks, shape, splits, pipes[r][1], str(tmp_path), K))
              for r in range(nranks)]
     for pr in procs:
         pr.start()

@@ -220,7 +220,7 @@ def _worker_march(rank, world, port, deck, ngroups, K, outdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,deck,ngroups,K", [(2, "128x256", 6, 4), (2, "128x128", 6, 4), (3, "128x128", 4, 4), (2, "128x256", 3, 6)])
+@pytest.mark.parametrize("world,deck,ngroups,K", [(2, "128x256", 6, 4), (2, "128x128", 6, 4), (3, "128x128", 4, 4), (2, "128x256", 3, 6), (2, "128x256", 3, 8), (3, "128x128", 2, 8)])
 def test_k_row_ghost_zone_of_the_marching_kernels(tmp_path, O, oracle, world, deck, ngroups, K):
     """K steps on a slab need K rows of each neighbour and nothing else (accelerate row included, wherever in the ghost
     zone its periodic image falls): what lbm_march reads in place across slabs (lbm_api.hip: launch_march_slabs, run_p2p),

@@ -15,9 +15,11 @@ for nx, ny, label in ((1024, 1024, "1 GPU"), (1024, 512, "rank of 2"), (1024, 25
     ob = np.zeros((ny, nx), np.int32)
     ob[:, 0] = ob[:, -1] = 1
     ob[:, nx // 3] = 1
-    steps = 4000 if nx == 1024 else 200
+    steps = 4000 if nx == 1024 else 208
     whole = (1024 * 1024 if nx == 1024 else 8192 * 8192) / (nx * ny)
-    for mode, name, tb in ((L.EXCHANGE_P2P, "p2p default", 0), (L.EXCHANGE_P2P, "p2p lbm_sweep2", 2), (L.EXCHANGE_RCCL, "rccl", 0)):
+    for mode, name, tb in ((L.EXCHANGE_P2P, "p2p default", 0), (L.EXCHANGE_P2P, "p2p lbm_wave<8>", 8), (L.EXCHANGE_P2P, "p2p lbm_sweep2", 2), (L.EXCHANGE_RCCL, "rccl", 0)):
+        if tb == 8 and ny < 32:
+            continue
         with L.Lattice(p, ob, rank=0, nranks=1, device=0, unique_id=L.rccl_unique_id(), exchange=mode) as lat:
             if tb:
                 lat.set_option("time_block", tb)
