@@ -102,10 +102,10 @@ def choose_exchange(p, ob, world, rank, local_rank):
         return L.EXCHANGE_AUTO, "none (periodic self-wrap)"
     if os.environ.get("LBM_BENCH_EXCHANGE", "") == "rccl":
         return L.EXCHANGE_RCCL, "RCCL send/recv (forced by LBM_BENCH_EXCHANGE)"
-    # ground truth for the self-check: the same 9 steps on the WHOLE lattice, alone on this rank's GPU
+    # ground truth for the self-check: the same 22 steps on the WHOLE lattice, alone on this rank's GPU
     # (every decomposition and transport is bit-identical to it by construction and by test)
     with L.Lattice(p, ob, nslabs=1, devices=[local_rank]) as whole:
-        av_true = np.concatenate([whole.run(6), whole.run(3)])
+        av_true = np.concatenate([whole.run(19), whole.run(3)])
         rb, re_ = L.slab_bounds(p.ny, world, rank)
         st_true = whole.read_state()[rb:re_].copy()
     probe_steps = 400 if p.nx * p.ny <= (1 << 22) else 40
@@ -123,7 +123,7 @@ def choose_exchange(p, ob, world, rank, local_rank):
         ok = all_ranks_agree(ok, world)
         if ok:
             try:
-                av = np.concatenate([lat.run(6), lat.run(3)])   # pairs, and an odd run: trailing single step
+                av = np.concatenate([lat.run(19), lat.run(3)])  # marching groups (8 or 4 steps), a pair, a single; then an odd run
                 st = lat.read_state()
                 if not (np.array_equal(st.view(np.uint32), st_true.view(np.uint32)) and
                         np.allclose(av, av_true, rtol=2e-6, atol=0)):
