@@ -1310,13 +1310,13 @@ int wave_slots(const lbm_ctx* c) { return std::max(c->ncu, 1) * std::max(wave_bl
 double slab_wave_efficiency(const lbm_ctx* c, int ny_rows, int h) {
   const long waves = (long)cdiv(c->p.nx, 64 - 16) * cdiv(ny_rows, h), slots = wave_slots(c);
   const double rounds = waves <= 2 * slots ? (double)((waves + slots - 1) / slots) : (double)waves / slots;   // (many rounds overlap)
-  return (double)waves / (rounds * slots) * h / (h + 16.0);
+  return (double)cdiv(c->p.nx, 64 - 16) * ny_rows / (rounds * slots * (h + 16.0));   // rows done per slot-iteration spent
 }
 int slab_wave_rows(const lbm_ctx* c, int ny_rows) {
   if (c->wave_rows > 0) return std::min(c->wave_rows, ny_rows);
   int best_h = std::min(ny_rows, 128);
   double best = -1.0;
-  for (int h = std::min(ny_rows, 32); h <= std::min(ny_rows, 128); h += 8) {     // (beyond 128 rows the chunks get slower: measured)
+  for (int h = std::min(ny_rows, 32); h <= std::min(ny_rows, 128); ++h) {        // (beyond 128 rows the chunks get slower: measured)
     const double e = slab_wave_efficiency(c, ny_rows, h);
     if (e > best + 1e-9) { best = e; best_h = h; }
   }
