@@ -680,6 +680,8 @@ bool march_slabs_setup(lbm_ctx* c);   // marching kernel across slabs, below
 template <int K> int wave_blocks_per_cu();   // occupancy of lbm_wave<K>, below
 bool p2p_march_pays(const lbm_ctx* c);
 bool slab_wave_pays(const lbm_ctx* c, int rows);
+int slab_wave_rows(const lbm_ctx* c, int ny_rows);
+double slab_wave_efficiency(const lbm_ctx* c, int ny_rows, int h);
 int march_rows_for(const lbm_ctx* c, int ny_rows);
 
 int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
@@ -736,16 +738,18 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
       else if (!use_wave_kernel(c)) { if (march_efficiency(c, march_pick_rows(c)) < 0.65) c->time_block = 2; }
       else if ((long)c->p.nx * c->p.ny < (3L << 20)) c->time_block = 2;   // lbm_wave needs a few thousand waves: from about 2048^2
       else c->time_block = 6;
-      // Eight steps per pass in registers (lbm_wave<8>, 10.5 B per update, bound by its arithmetic) overtakes lbm_march
-      // (19.4 B, bound by HBM) once the lattice gives every wave slot of the chip three chunks of 128 rows to work
-      // through: measured in one call at 8192^2 304 against 284 GLUPS (4096^2: 262 against 286, 2048^2: 217 against 231).
-      if (c->time_block == 4 && c->march_kernel < 0 && !getenv("LBM_MARCH_KERNEL") && c->p.nx >= 64 && c->p.ny >= 128 &&
+      // Eight steps per pass in registers (lbm_wave<8>, 10.5 B per update, bound by its arithmetic) against lbm_march
+      // (19.4 B, bound by HBM): each priced by what it does with a full chip -- 371 and 300 GLUPS -- times the share of
+      // its slot-iterations that are useful with the best chunk height.  Measured in one call, lbm_wave<8> with the
+      // chunk height of the model / lbm_march: 8192^2 328 / 284, 7168^2 329 / 299, 6144^2 325 / 302, 5120^2 310 / 294
+      // (91-row chunks = 1.99 rounds; 87 rows = 2.06 rounds: 282), 4608^2 308 / 295, 4096^2 287 / 280, 3072^2 265 / 259,
+      // 2048^2 201 / 230.
+      if (c->time_block == 4 && c->march_kernel < 0 && !getenv("LBM_MARCH_KERNEL") && c->p.nx >= 64 && c->p.ny >= 32 &&
           (double)c->p.ny * c->slabs[0].pitch * 4.0 < 4.0e9) {
-        const long waves = (long)cdiv(c->p.nx, 64 - 2 * 8) * cdiv(c->p.ny, 128);
-        const long slots = (long)std::max(c->ncu, 1) * std::max(wave_blocks_per_cu<8>(), 1) * (lbm::kWaveBlock / 64);
-        if (waves >= 3 * slots) {
+        const int h = slab_wave_rows(c, c->p.ny);
+        if (371.0 * slab_wave_efficiency(c, c->p.ny, h) >= 300.0 * march_efficiency(c, march_pick_rows(c))) {
           c->time_block = 8; c->march_kernel = 1;
-          if (c->wave_rows <= 0) c->wave_rows = 128;
+          if (c->wave_rows <= 0) c->wave_rows = h;
         }
       }
     }
@@ -1307,10 +1311,18 @@ int march_rows_for(const lbm_ctx* c, int ny_rows) {
 // Rows per chunk of lbm_wave<8> on a slab of ny_rows rows, and the share of the chip's wave-slot time that is useful
 // work with it: a chunk costs 2K fill iterations, and waves that do not fill the last round leave slots idle.
 int wave_slots(const lbm_ctx* c) { return std::max(c->ncu, 1) * std::max(wave_blocks_per_cu<8>(), 1) * (lbm::kWaveBlock / 64); }
+// The share of the chip's wave-slot time that is useful work with chunks of h rows: a chunk costs its 2K fill
+// iterations on top of its h, and the waves come in rounds of `slots`: up to three rounds a partial round costs a whole
+// one (4096^2: 118-row chunks = 0.98 rounds 285 GLUPS, 114-row chunks = 1.008 rounds 231; 5120^2: 91 rows = 1.99 rounds
+// 310, 87 rows = 2.06 rounds 282), beyond that the rounds blur into each other.  A single round, in which every wave
+// fills at the same time, runs ~0.87 of what this predicts, several rounds ~0.94 (371 GLUPS x this figure against the
+// measured rates of 2048^2 ... 8192^2 and of the 8192-wide slabs).
 double slab_wave_efficiency(const lbm_ctx* c, int ny_rows, int h) {
   const long waves = (long)cdiv(c->p.nx, 64 - 16) * cdiv(ny_rows, h), slots = wave_slots(c);
-  const double rounds = waves <= 2 * slots ? (double)((waves + slots - 1) / slots) : (double)waves / slots;   // (many rounds overlap)
-  return (double)cdiv(c->p.nx, 64 - 16) * ny_rows / (rounds * slots * (h + 16.0));   // rows done per slot-iteration spent
+  const double r = (double)waves / slots;
+  const double rounds = r <= 3.0 ? std::ceil(r) : r;
+  const double shape = rounds <= 1.0 ? 0.87 : 0.94;
+  return shape * (double)cdiv(c->p.nx, 64 - 16) * ny_rows / (rounds * slots * (h + 16.0));
 }
 int slab_wave_rows(const lbm_ctx* c, int ny_rows) {
   if (c->wave_rows > 0) return std::min(c->wave_rows, ny_rows);
