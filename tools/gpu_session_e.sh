@@ -2,7 +2,7 @@
 # Round-2 GPU session E: full GPU suite, driver-style + default bench, kernel trace + PMC traffic of the
 # default kernels, CLI on the generated 8192^2 deck.
 set -o pipefail
-O=gpurun_out/r02p
+O=gpurun_out/r02q
 mkdir -p $O
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
