@@ -881,6 +881,14 @@ def test_marching_kernel_is_the_default_on_big_lattices_only(gpu):
         with L.Lattice(p, np.zeros((n, n), dtype=np.int32)) as lat:
             assert lat.info("time_block_active") == want, n
             assert lat.info("march_kernel") == 0                   # lbm_march wherever it can run
+    # from ~5000^2 up: eight steps per pass in registers (lbm_wave<8>), chunk height such that the waves come in whole
+    # rounds of the chip's wave slots (5120^2: 107 wave columns x 57 chunks of 90 rows = 6099 waves for 2 x 3072 slots)
+    for n, rows_ok in ((5120, (90, 91)), (8192, (128,))):
+        p = L.Param(n, n, 10, 10, 0.1, 0.01, 1.85)
+        with L.Lattice(p, np.zeros((n, n), dtype=np.int32)) as lat:
+            assert lat.info("time_block_active") == 8 and lat.info("march_kernel") == 1, n
+            if lat.info("compute_units") == 256 and lat.info("wave_capacity") in (0, 3072):
+                assert int(lat.info("wave_rows")) in rows_ok, (n, lat.info("wave_rows"))
     # a width lbm_march cannot take (not a multiple of 4): lbm_wave<6> on a big lattice
     p = L.Param(2050, 2048, 10, 10, 0.1, 0.01, 1.85)
     with L.Lattice(p, np.zeros((2048, 2050), dtype=np.int32)) as lat:
