@@ -32,7 +32,6 @@
 
 #include "../../include/lbm_mi355x.h"
 #include "lbm_kernels.hip.h"
-#include "lbm_resident.hip.h"
 #include "lbm_march.hip.h"
 #include "lbm_wave.hip.h"
 #include "lbm_regtile.hip.h"
@@ -198,20 +197,22 @@ struct lbm_ctx {
   // engine: which kernel family lbm_run uses for a lattice alone on its GPU
   //   0 auto = the register-resident kernel (lbm_regtile) where the lattice tiles onto the CUs (the four
   //   shipped decks: 1.5-2x the streaming kernels), the streaming kernels elsewhere,
-  //   1 streaming only (lbm_sweep2 / lbm_sweep), 2 resident in LDS (lbm_resident) or fail,
-  //   3 resident in registers (lbm_regtile) or fail
+  //   1 streaming only (lbm_sweep2 / lbm_sweep / the marching kernels),
+  //   3 resident in registers (lbm_regtile) or fail   (2 was the LDS-resident engine, removed in round 3)
   int engine = 0;
-  int engine_last = 0;         // what the last lbm_run used: 1 streaming, 2 resident
-  struct { int tx = 0, ty = 0, v = 0, threads = 0, ntx = 0, nty = 0; } rplan;   // resident tiling (tx == 0: none)
-  struct { int ty = 0, r = 0, nw = 0, ntx = 0, nty = 0; } tplan;   // register-tile engine (engine 3): 64 x ty tiles, nw waves of r rows (ty == 0: none)
+  int engine_last = 0;         // what the last lbm_run used: 1 streaming, 3 resident in registers
+  // register-tile engine (engine 3): 64 x ty tiles, nw waves of r rows (ty == 0: none); bpc = blocks of this tiling a CU
+  // takes by the occupancy query (0 = not asked yet, -1 = the query failed or the grid does not fit)
+  struct { int ty = 0, r = 0, nw = 0, ntx = 0, nty = 0, bpc = 0; } tplan;
   unsigned long long* tmail = nullptr;   // its mailboxes
-  unsigned long long* rmail = nullptr;   // resident mailboxes
   float* rpartials = nullptr;  // [steps][tiles]
   long rpartials_cap = 0;      // in steps
   int rpartials_tiles = 0;     // tiles per step it was sized for
   uint32_t* rabort = nullptr;  // device abort word of the resident kernel
-  uint32_t rtag = 1;           // next unused mailbox tag (0 = never written)
-  bool resident_broken = false;   // a resident run gave up on this device: stay with the streaming kernels
+  uint32_t rtag = 1;           // next unused mailbox tag (0 = never written); never goes back except when the mailboxes are cleared
+  bool resident_broken = false;   // the resident kernel cannot run here (not every tile resident, set-up failed, or a run
+                                  // gave up): stay with the streaming kernels
+  char resident_why[160] = "";    // ... and why (lbm_last_error does not carry it: the run itself succeeds)
   int ncu = 0;                 // CUs of slab 0's device
   double gpu_ms = 0.0, wall_ms = 0.0;
 };
@@ -438,7 +439,7 @@ void pick_defaults(lbm_ctx* c) {
   }
   const char* e;
   if ((e = getenv("LBM_VECTOR_WIDTH"))) c->V = pick_vector_width(nx);
-  if ((e = getenv("LBM_KERNEL_VARIANT"))) c->variant = atol(e) & 7;
+  if ((e = getenv("LBM_KERNEL_VARIANT"))) c->variant = atol(e) & 15;
   if ((e = getenv("LBM_TIME_BLOCK"))) { const int v = atoi(e); c->time_block = (v == 8 || v == 6 || v == 4 || v == 2) ? v : 1; }
   if ((e = getenv("LBM_MARCH_KERNEL"))) c->march_kernel = atoi(e) == 0 ? 0 : atoi(e) == 1 ? 1 : -1;
   if ((e = getenv("LBM_WAVE_ROWS")) && atoi(e) > 0) c->wave_rows = std::min(atoi(e), c->p.ny);
@@ -449,7 +450,7 @@ void pick_defaults(lbm_ctx* c) {
 // The two-step kernel covers whole 64 x 16 tiles.  With neighbours every slab must tile too,
 // and every rank must come to the same answer (the halo message size depends on it).
 bool t2_eligible(const lbm_ctx* c) {
-  if (c->time_block < 2) return false;
+  if (c->time_block < 2 || (c->variant & 8)) return false;   // (variant bit 3: the reference's speed sum, one-step kernel only)
   // a slab alone: any lattice of at least one tile (partial tiles at the east / north end)
   if (c->exchange == 0) return c->slabs.size() == 1 && c->p.nx >= kT2X && c->p.ny >= kT2Y;
   return c->p.nx % kT2X == 0 && c->p.ny % (c->nranks * kT2Y) == 0;
@@ -465,9 +466,12 @@ inline bool march_block_ok(const lbm_ctx* c) {   // lbm_march's own requirements
 }
 inline bool use_wave_kernel(const lbm_ctx* c) { return c->march_kernel == 1 || (c->march_kernel < 0 && !march_block_ok(c)); }
 bool march_eligible(const lbm_ctx* c) {
-  if (c->time_block < 4 || c->exchange != 0 || c->slabs.size() != 1) return false;
+  if (c->time_block < 4 || c->exchange != 0 || c->slabs.size() != 1 || (c->variant & 8)) return false;
   if ((double)c->p.ny * c->slabs[0].pitch * 4.0 >= 4.0e9) return false;   // 32-bit byte offsets inside a plane
-  if (use_wave_kernel(c)) return c->p.nx >= 64 && c->p.ny >= 2;           // lbm_wave: any width of at least one wave
+  // lbm_wave: any width of at least one wave; ny >= 2K because the kernel applies the accelerate phase at two
+  // periodic images of row ny-2 per chunk (lbm_wave.hip.h: jacc, jacc2) and a chunk plus its 2K fill rows spans
+  // up to ny + 2K rows: on a shorter lattice a third image would fall among them
+  if (use_wave_kernel(c)) return c->p.nx >= 64 && c->p.ny >= 2 * c->time_block;
   return march_block_ok(c);
 }
 
@@ -577,10 +581,12 @@ void launch_sweep_vm(const lbm::SweepArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((lbm::lbm_sweep<V, MODE>), dim3(grid), dim3(lbm::kBlock), 0, st, a);
 }
 
-// variant = lbm::kFastMath | kNtStore | kNtLoad bits (option "kernel_variant")
+// variant = lbm::kFastMath | kNtStore | kNtLoad bits (option "kernel_variant"); bit 3 (value 8) = the step's average
+// speed re-summed from the stored populations, the reference's form (lbm::kSpeedFromStored; one-step kernel only)
 template <int V>
 void launch_sweep_v(const lbm::SweepArgs& a, hipStream_t st, long variant) {
-  switch (variant & 7) {
+  constexpr int S = lbm::kSpeedFromStored;
+  switch (variant & 15) {
     case 0: launch_sweep_vm<V, 0>(a, st); break;
     case 1: launch_sweep_vm<V, 1>(a, st); break;
     case 2: launch_sweep_vm<V, 2>(a, st); break;
@@ -588,7 +594,15 @@ void launch_sweep_v(const lbm::SweepArgs& a, hipStream_t st, long variant) {
     case 4: launch_sweep_vm<V, 4>(a, st); break;
     case 5: launch_sweep_vm<V, 5>(a, st); break;
     case 6: launch_sweep_vm<V, 6>(a, st); break;
-    default: launch_sweep_vm<V, 7>(a, st); break;
+    case 7: launch_sweep_vm<V, 7>(a, st); break;
+    case 8: launch_sweep_vm<V, S | 0>(a, st); break;
+    case 9: launch_sweep_vm<V, S | 1>(a, st); break;
+    case 10: launch_sweep_vm<V, S | 2>(a, st); break;
+    case 11: launch_sweep_vm<V, S | 3>(a, st); break;
+    case 12: launch_sweep_vm<V, S | 4>(a, st); break;
+    case 13: launch_sweep_vm<V, S | 5>(a, st); break;
+    case 14: launch_sweep_vm<V, S | 6>(a, st); break;
+    default: launch_sweep_vm<V, S | 7>(a, st); break;
   }
 }
 
@@ -674,8 +688,7 @@ int ensure_sums(Slab& s, int nsteps) {
   return LBM_OK;
 }
 
-bool plan_resident(lbm_ctx* c);   // resident engines, below
-bool plan_regtile(lbm_ctx* c);
+bool plan_regtile(lbm_ctx* c);    // resident engine, below
 bool march_slabs_setup(lbm_ctx* c);   // marching kernel across slabs, below
 template <int K> int wave_blocks_per_cu();   // occupancy of lbm_wave<K>, below
 bool p2p_march_pays(const lbm_ctx* c);
@@ -703,8 +716,8 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
     if (hipGetDeviceProperties(&prop, c->slabs[0].dev) == hipSuccess) c->ncu = prop.multiProcessorCount;
     else (void)hipGetLastError();
     const char* e = getenv("LBM_ENGINE");
-    if (e) c->engine = (atoi(e) >= 0 && atoi(e) <= 3) ? atoi(e) : 0;
-    if (!exchanging && c->slabs.size() == 1) { plan_resident(c); plan_regtile(c); }
+    if (e) c->engine = (atoi(e) == 0 || atoi(e) == 1 || atoi(e) == 3) ? atoi(e) : 0;
+    if (!exchanging && c->slabs.size() == 1) plan_regtile(c);
     // Four steps per pass (lbm_march) where its strips and chunks fill the chip: measured 1.5-1.6x
     // lbm_sweep2 from 2048^2 up (194 / 226 / 238 GLUPS at 2048^2 / 4096^2 / 8192^2 against 129 / 146 /
     // 150), 0.8x at 1024^2, where 5 strips x 32-row chunks leave the CUs 49 % busy by the estimate
@@ -1289,7 +1302,7 @@ bool march_slabs_setup(lbm_ctx* c) {
 }
 // Steps per marching pass of a context whose slabs trade rows: 8 = lbm_wave<8>, 4 = lbm_march, 0 = no marching.
 inline int slab_K(const lbm_ctx* c) {
-  if (c->exchange == 0) return 0;
+  if (c->exchange == 0 || (c->variant & 8)) return 0;
   if (c->time_block == 8) return (c->p.nx >= 64) ? 8 : 0;
   if (c->time_block == kMarchK) return (c->p.nx % 4 == 0 && c->p.nx >= lbm::MarchCfg<kMarchK>::W) ? kMarchK : 0;
   return 0;
@@ -1482,6 +1495,32 @@ inline int wave_blocks(const lbm_ctx* c) {
   return cdiv((long)cdiv(c->p.nx, 64 - 2 * c->time_block) * cdiv(c->p.ny, c->wave_rows), lbm::kWaveBlock / 64);
 }
 
+// The blocks of one marching launch must fit the per-block partial sums (K floats per block).  Asked BEFORE anything
+// of a run is queued -- behind the prologue the lattice would already carry the accelerate phase of a step that is
+// then never taken -- and when the chunk heights are set.
+int check_march_partials(lbm_ctx* c, bool slabs_march) {
+  if (slabs_march) {
+    const int K = slab_K(c);
+    for (auto& s : c->slabs) {
+      const long nb = march_slab_blocks(c, s);
+      if ((long)K * nb > s.partial_cap) return fail(LBM_EINVAL, "marching kernel: %ld blocks exceed the partial-sum buffer (raise wave_rows / march_rows)", nb);
+    }
+  } else if (march_eligible(c)) {
+    const int K = c->time_block;
+    long nb;
+    if (use_wave_kernel(c)) {
+      if (c->wave_rows <= 0 || c->wave_capacity <= 0) wave_plan(c);
+      nb = wave_blocks(c);
+    } else {
+      if (c->march_rows <= 0) c->march_rows = march_pick_rows(c);
+      nb = (long)cdiv(c->p.nx, lbm::MarchCfg<kMarchK>::WOUT) * cdiv(c->p.ny, c->march_rows);
+    }
+    if ((long)K * nb > c->slabs[0].partial_cap)
+      return fail(LBM_EINVAL, "marching kernel: %ld blocks exceed the partial-sum buffer (raise wave_rows / march_rows)", nb);
+  }
+  return LBM_OK;
+}
+
 }  // namespace
 
 namespace {
@@ -1531,142 +1570,24 @@ int collect_sums(lbm_ctx* c, int nsteps, float* av_vels, std::chrono::steady_clo
 }
 
 // ----------------------------------------------------------------- resident engine
-// Tile shapes lbm_resident accepts: tx = v * 2^m with at most 64 lanes per tile row, tx | nx,
-// ty | ny, tx * ty <= kResidentMaxCells, (tx / v) * ty threads (rounded up to whole waves) <= 1024,
-// and at most one tile per CU (every tile must be resident at once: grid <= CUs is what guarantees
-// it, cdna_hip_programming.md §1).
-bool resident_tile_ok(const lbm_ctx* c, int tx, int ty, int v) {
-  const int nx = c->p.nx, ny = c->p.ny;
-  if (!(v == 1 || v == 2 || v == 4) || tx < v || ty < 1 || tx % v) return false;
-  const int lanes = tx / v;
-  if (lanes > 64 || (lanes & (lanes - 1)) != 0) return false;
-  if (tx > nx || ty > ny || nx % tx || ny % ty) return false;
-  if ((long)tx * ty > lbm::kResidentMaxCells) return false;
-  if ((lanes * ty + 63) / 64 * 64 > 1024) return false;
-  return (long)(nx / tx) * (ny / ty) <= c->ncu;
-}
-
-void resident_set_plan(lbm_ctx* c, int tx, int ty, int v) {
-  c->rplan.tx = tx; c->rplan.ty = ty; c->rplan.v = v;
-  c->rplan.threads = ((tx / v) * ty + 63) / 64 * 64;
-  c->rplan.ntx = c->p.nx / tx; c->rplan.nty = c->p.ny / ty;
-}
-
-// Picks the tiling with the lowest estimated time per step (cycles per CU): arithmetic
-// (about 115 VALU instructions per cell; a SIMD retires one wave-instruction every 2 cycles, a
-// lone wave every 4), LDS traffic of the pull and push, and the hand-off with the neighbours
-// (about 1 us of latency plus a term in the tile's perimeter).
-bool plan_resident(lbm_ctx* c) {
-  c->rplan.tx = 0;
-  if (c->ncu < 1) return false;
-  double best = 1e30;
-  for (int v : {4, 2, 1})
-    for (int m = 0; m <= 6; ++m) {
-      const int tx = v << m;
-      for (int ty = 1; ty <= c->p.ny && (long)tx * ty <= lbm::kResidentMaxCells; ++ty) {
-        if (!resident_tile_ok(c, tx, ty, v)) continue;
-        const int waves = ((tx / v) * ty + 63) / 64, wps = (waves + 3) / 4;
-        const double valu = (double)wps * v * 115.0 * (wps == 1 ? 4.0 : 2.0);
-        const double lds = (double)waves * 9.0 * ((v == 4 ? 4.0 : 2.0) + (v == 4 ? 13.0 : v == 2 ? 6.0 : 4.0));
-        const double cost = std::max(valu, lds) + 2000.0 + 4.0 * (tx + ty);
-        if (cost < best) { best = cost; resident_set_plan(c, tx, ty, v); }
-      }
-    }
-  return c->rplan.tx > 0;
-}
-
 void resident_free(lbm_ctx* c) {
   if (c->slabs.empty()) return;
   (void)hipSetDevice(c->slabs[0].dev);
-  if (c->rmail) (void)hipFree(c->rmail);
   if (c->tmail) (void)hipFree(c->tmail);
   c->tmail = nullptr; c->rpartials_tiles = 0;
   if (c->rpartials) (void)hipFree(c->rpartials);
   if (c->rabort) (void)hipFree(c->rabort);
-  c->rmail = nullptr; c->rpartials = nullptr; c->rabort = nullptr; c->rpartials_cap = 0;
+  c->rpartials = nullptr; c->rabort = nullptr; c->rpartials_cap = 0;
 }
 
-template <int V>
-void launch_resident_v(const lbm_ctx* c, const lbm::ResidentArgs& a, int grid, int threads, hipStream_t st) {
-  const char* dbg = getenv("LBM_RESIDENT_DEBUG");   // timing experiments (wrong results): see lbm_resident.hip.h
-  if (dbg && atoi(dbg) == 1) { hipLaunchKernelGGL((lbm::lbm_resident<V, lbm::kFastMath | lbm::kResDebugNoWait>), dim3(grid), dim3(threads), 0, st, a); return; }
-  if (dbg && atoi(dbg) == 2) { hipLaunchKernelGGL((lbm::lbm_resident<V, lbm::kFastMath | lbm::kResDebugNoWait | lbm::kResDebugNoSend>), dim3(grid), dim3(threads), 0, st, a); return; }
-  if (c->variant & lbm::kFastMath) hipLaunchKernelGGL((lbm::lbm_resident<V, lbm::kFastMath>), dim3(grid), dim3(threads), 0, st, a);
-  else hipLaunchKernelGGL((lbm::lbm_resident<V, 0>), dim3(grid), dim3(threads), 0, st, a);
-}
-
-// The whole run in one launch (lbm_resident.hip.h).  *done = false with LBM_OK means the kernel
-// gave up (a tile never heard from a neighbour: not every tile was resident): the source lattice
-// is untouched and the caller repeats the run with the streaming kernels.
-int run_resident(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
-  *done = false;
-  Slab& s = c->slabs[0];
-  HIPC(hipSetDevice(s.dev));
-  const auto& r = c->rplan;
-  const int ntiles = r.ntx * r.nty;
-  const size_t mail_bytes = sizeof(unsigned long long) * (size_t)ntiles * 2 * 8 * (size_t)(r.tx + r.ty);
-  if (!c->rmail) {
-    HIPC(hipMalloc((void**)&c->rmail, mail_bytes));
-    HIPC(hipMemsetAsync(c->rmail, 0, mail_bytes, s.sc));
-    c->rtag = 1;
-    if (!c->rabort) {
-      HIPC(hipMalloc((void**)&c->rabort, 64));
-      HIPC(hipMemsetAsync(c->rabort, 0, 64, s.sc));
-    }
-  }
-  if ((unsigned long long)c->rtag + (unsigned long long)nsteps >= 0x7fffff00ull) {   // tags would wrap: start over
-    HIPC(hipMemsetAsync(c->rmail, 0, mail_bytes, s.sc));
-    c->rtag = 1;
-  }
-  if (c->rpartials_cap < nsteps || c->rpartials_tiles < ntiles) {
-    long cap = std::max(1024L, c->rpartials_cap);
-    while (cap < nsteps) cap *= 2;
-    if (c->rpartials) HIPC(hipFree(c->rpartials));
-    c->rpartials = nullptr; c->rpartials_cap = 0;
-    const int tiles = std::max(ntiles, c->rpartials_tiles);
-    HIPC(hipMalloc((void**)&c->rpartials, sizeof(float) * (size_t)cap * tiles));
-    c->rpartials_cap = cap; c->rpartials_tiles = tiles;
-  }
-  int rc = ensure_sums(s, nsteps);
-  if (rc) return rc;
-
-  lbm::ResidentArgs a;
-  a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
-  a.plane = s.plane; a.pitch = s.pitch; a.nx = c->p.nx; a.ny = c->p.ny;
-  a.blocked = s.blocked; a.omega = c->p.omega;
-  a.accel_row = c->p.ny - 2;
-  a.a1 = c->p.density * c->p.accel / 9.f; a.a2 = c->p.density * c->p.accel / 36.f;
-  a.tx = r.tx; a.ty = r.ty; a.ntx = r.ntx; a.nty = r.nty;
-  a.nsteps = nsteps;
-  a.tag0 = c->rtag;
-  a.mail = c->rmail; a.partials = c->rpartials; a.abort_word = c->rabort;
-  c->rtag += (uint32_t)nsteps;
-
-  s.err_host[1] = 0;   // lbm_fold_steps stores the abort word here
-  const auto wall0 = std::chrono::steady_clock::now();
-  HIPC(hipEventRecord(s.ev_t0, s.sc));
-  switch (r.v) {
-    case 4: launch_resident_v<4>(c, a, ntiles, r.threads, s.sc); break;
-    case 2: launch_resident_v<2>(c, a, ntiles, r.threads, s.sc); break;
-    default: launch_resident_v<1>(c, a, ntiles, r.threads, s.sc); break;
-  }
-  HIPC(hipGetLastError());
-  hipLaunchKernelGGL(lbm::lbm_fold_steps, dim3(cdiv(nsteps, lbm::kBlock / 64)), dim3(lbm::kBlock), 0, s.sc,
-                     c->rpartials, ntiles, nsteps, s.sums, c->rabort, s.err_host + 1);
-  HIPC(hipGetLastError());
-  HIPC(hipEventRecord(s.ev_t1, s.sc));
-  rc = collect_sums(c, nsteps, av_vels, wall0);
-  if (rc) return rc;
-  if (s.err_host[1] != 0) {
-    c->resident_broken = true;
-    HIPC(hipMemsetAsync(c->rabort, 0, 64, s.sc));
-    HIPC(hipStreamSynchronize(s.sc));
-    if (getenv("LBM_VERBOSE")) fprintf(stderr, "lbm: the resident kernel gave up (a tile was not scheduled); using the streaming kernels\n");
-    return LBM_OK;
-  }
-  c->cur ^= 1;
-  *done = true;
-  return LBM_OK;
+// The resident engine cannot be used on this context (any more): remember why, say so ONCE on stderr (a run that quietly
+// takes twice as long is worse than a line of text), carry on with the streaming kernels.
+void resident_give_up(lbm_ctx* c, const char* why) {
+  c->resident_broken = true;
+  snprintf(c->resident_why, sizeof(c->resident_why), "%s", why);
+  static bool said = false;
+  if (!said || getenv("LBM_VERBOSE")) fprintf(stderr, "lbm: register-tile engine not used (%s); running the streaming kernels instead\n", why);
+  said = true;
 }
 
 // ---- register-tile engine (lbm_regtile.hip.h): 64-column tiles of nw x r rows, one per CU
@@ -1680,6 +1601,7 @@ bool regtile_ok(const lbm_ctx* c, int ty, int r) {
 }
 void regtile_set(lbm_ctx* c, int ty, int r) {
   c->tplan.ty = ty; c->tplan.r = r; c->tplan.nw = ty / r; c->tplan.ntx = c->p.nx / 64; c->tplan.nty = c->p.ny / ty;
+  c->tplan.bpc = 0;          // (the residency of this tiling has not been asked yet)
 }
 // Default tiling.  A step is bounded by the hand-off with the neighbouring tiles (about 1.6 us) plus the serial
 // work of one wave, so: as few rows per wave as the lattice allows (1, then 2, then 4), and tiles of several
@@ -1696,16 +1618,48 @@ bool plan_regtile(lbm_ctx* c) {
   return false;
 }
 
-// One launch of lbm_regtile<R, MODE>; its LDS is dynamic and may exceed the 64 KB a kernel gets without asking.
-template <int R, int MODE>
-void launch_regtile(dim3 grid, dim3 block, unsigned shm, hipStream_t st, const lbm::RegTileArgs& a) {
-  static bool raised = false;
-  if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbm::lbm_regtile<R, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    raised = true;
+// The instantiation of lbm_regtile for a tiling and flavour (dbg: the LBM_RESIDENT_DEBUG timing experiments, R = 4 only).
+typedef void (*regtile_fn)(const lbm::RegTileArgs);
+regtile_fn regtile_kernel(int r, bool fast, int dbg, bool trace) {
+  constexpr int NW_ = lbm::kResDebugNoWait, NS_ = lbm::kResDebugNoSend;
+  if (r == 4 && dbg == 1) return lbm::lbm_regtile<4, NW_>;
+  if (r == 4 && dbg == 2) return lbm::lbm_regtile<4, NW_ | NS_>;
+  if (r == 4 && dbg == 3) return lbm::lbm_regtile<4, NW_ | NS_ | 256>;
+  if (r == 4 && dbg == 4) return lbm::lbm_regtile<4, NW_ | 512>;
+  if (r == 4 && dbg == 5) return lbm::lbm_regtile<4, NW_ | 1024>;
+  if (r == 4 && trace) return lbm::lbm_regtile<4, 2048>;
+  switch (r) {
+    case 4: return fast ? lbm::lbm_regtile<4, 1> : lbm::lbm_regtile<4, 0>;
+    case 2: return fast ? lbm::lbm_regtile<2, 1> : lbm::lbm_regtile<2, 0>;
+    default: return fast ? lbm::lbm_regtile<1, 1> : lbm::lbm_regtile<1, 0>;
   }
-  hipLaunchKernelGGL((lbm::lbm_regtile<R, MODE>), grid, block, shm, st, a);
+}
+
+// Before the first launch of a tiling on a device: let the kernel have its dynamic LDS (beyond the 64 KB a kernel gets
+// without asking) and ASK the runtime how many of its blocks a CU takes.  The tiles wait on each other, so all of them must
+// be resident at once: blocks per CU x CUs >= tiles, or the launch would stall until its waits time out.  Returns the
+// blocks per CU, or -1 with the reason in lbm_last_error.
+int regtile_prepare(const lbm_ctx* c, regtile_fn fn, int dev, int threads, unsigned shm) {
+  struct Seen { regtile_fn fn; int dev; };
+  static std::mutex mu;
+  static std::vector<Seen> raised;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    bool have = false;
+    for (auto& e : raised) have = have || (e.fn == fn && e.dev == dev);
+    if (!have) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (shm > 64u * 1024u) { fail(LBM_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e)); return -1; }
+      } else raised.push_back({fn, dev});
+    }
+  }
+  int n = 0;
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(fn), threads, shm);
+  if (e != hipSuccess) { (void)hipGetLastError(); fail(LBM_EHIP, "occupancy query failed: %s", hipGetErrorString(e)); return -1; }
+  (void)c;
+  return n;
 }
 
 int run_regtile(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
@@ -1715,6 +1669,22 @@ int run_regtile(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
   const auto& t = c->tplan;
   const int ntiles = t.ntx * t.nty;
   const size_t mail_bytes = (size_t)ntiles * 2 * (size_t)lbm::regtile_box(t.ty);
+  const bool fast = (c->variant & lbm::kFastMath) != 0;
+  const dim3 grid(ntiles), block(64 * t.nw);
+  const unsigned shm = (unsigned)lbm::regtile_lds_bytes(t.nw, t.r);
+  const char* dbg = getenv("LBM_RESIDENT_DEBUG");   // timing experiments (wrong results): see lbm_regtile.hip.h
+  static const bool want_stats = getenv("LBM_REGTILE_STATS") != nullptr;   // development: missed polls per run, and a trace
+  const regtile_fn fn = regtile_kernel(t.r, fast, dbg ? atoi(dbg) : 0, want_stats && getenv("LBM_REGTILE_TRACE"));
+  if (c->tplan.bpc == 0) {                             // first run of this tiling: is every tile resident at once?
+    const int n = regtile_prepare(c, fn, s.dev, (int)block.x, shm);
+    c->tplan.bpc = (n < 0) ? -1 : n;
+    if (n < 0) snprintf(c->resident_why, sizeof(c->resident_why), "%s", lbm_last_error());
+    else if ((long)n * std::max(c->ncu, 1) < (long)ntiles) {
+      c->tplan.bpc = -1;
+      snprintf(c->resident_why, sizeof(c->resident_why), "%d tiles of %d waves, but the device takes %d block(s) per CU on %d CUs at once", ntiles, t.nw, n, c->ncu);
+    }
+  }
+  if (c->tplan.bpc < 0) return fail(LBM_EINVAL, "register tiling not usable: %s", c->resident_why);
   if (!c->tmail) {
     HIPC(hipMalloc((void**)&c->tmail, mail_bytes));
     HIPC(hipMemsetAsync(c->tmail, 0, mail_bytes, s.sc));
@@ -1723,13 +1693,14 @@ int run_regtile(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
       HIPC(hipMemsetAsync(c->rabort, 0, 64, s.sc));
     }
   }
-  if ((unsigned long long)c->rtag + (unsigned long long)nsteps >= 0x7fffff00ull) {   // tags would wrap: start over
+  // Tags only ever grow (a freshly zeroed mailbox is valid for any tag >= 1), except here: before they would wrap, the
+  // mailboxes are cleared and the count starts over.
+  if ((unsigned long long)c->rtag + (unsigned long long)nsteps >= 0x7fffff00ull) {
     HIPC(hipMemsetAsync(c->tmail, 0, mail_bytes, s.sc));
-    if (c->rmail) HIPC(hipMemsetAsync(c->rmail, 0, sizeof(unsigned long long) * (size_t)(c->rplan.ntx * c->rplan.nty) * 2 * 8 * (size_t)(c->rplan.tx + c->rplan.ty), s.sc));
     c->rtag = 1;
   }
-  // per-step tile sums (shared with the LDS-resident engine: sized for the larger tile count)
-  const int rtiles = std::max(ntiles, c->rplan.ntx * c->rplan.nty);
+  // per-step tile sums
+  const int rtiles = ntiles;
   if (c->rpartials_cap < nsteps || c->rpartials_tiles < rtiles) {
     long cap = std::max(1024L, c->rpartials_cap);
     while (cap < nsteps) cap *= 2;
@@ -1751,7 +1722,6 @@ int run_regtile(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
   a.mail = c->tmail; a.mail_bytes = (unsigned)mail_bytes; a.partials = c->rpartials; a.abort_word = c->rabort;
   a.fault = getenv("LBM_REGTILE_FAULT") ? 1 : 0;   // (tests: a tile that never starts)
   a.stats = nullptr;
-  static const bool want_stats = getenv("LBM_REGTILE_STATS") != nullptr;   // development: missed polls per run, and a trace
   static unsigned long long* stats_buf = nullptr;
   constexpr size_t kStatsWords = 4 + 16 * 4 * 16;
   if (want_stats) {
@@ -1767,26 +1737,7 @@ int run_regtile(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
   s.err_host[1] = 0;   // lbm_fold_steps stores the abort word here
   const auto wall0 = std::chrono::steady_clock::now();
   HIPC(hipEventRecord(s.ev_t0, s.sc));
-  const bool fast = (c->variant & lbm::kFastMath) != 0;
-  const dim3 grid(ntiles), block(64 * t.nw);
-  const unsigned shm = (unsigned)lbm::regtile_lds_bytes(t.nw, t.r);
-  const char* dbg = getenv("LBM_RESIDENT_DEBUG");   // timing experiments (wrong results): see lbm_regtile.hip.h
-  const int dv = dbg ? atoi(dbg) : 0;
-  if (dv >= 1 && dv <= 5 && t.r == 4) {
-    constexpr int NW_ = lbm::kResDebugNoWait, NS_ = lbm::kResDebugNoSend;
-    if (dv == 1) launch_regtile<4, NW_>(grid, block, shm, s.sc, a);
-    if (dv == 2) launch_regtile<4, NW_ | NS_>(grid, block, shm, s.sc, a);
-    if (dv == 3) launch_regtile<4, NW_ | NS_ | 256>(grid, block, shm, s.sc, a);
-    if (dv == 4) launch_regtile<4, NW_ | 512>(grid, block, shm, s.sc, a);
-    if (dv == 5) launch_regtile<4, NW_ | 1024>(grid, block, shm, s.sc, a);
-  } else if (t.r == 4 && want_stats && getenv("LBM_REGTILE_TRACE")) {
-    launch_regtile<4, 2048>(grid, block, shm, s.sc, a);
-  } else
-  switch (t.r) {
-    case 4: if (fast) launch_regtile<4, 1>(grid, block, shm, s.sc, a); else launch_regtile<4, 0>(grid, block, shm, s.sc, a); break;
-    case 2: if (fast) launch_regtile<2, 1>(grid, block, shm, s.sc, a); else launch_regtile<2, 0>(grid, block, shm, s.sc, a); break;
-    default: if (fast) launch_regtile<1, 1>(grid, block, shm, s.sc, a); else launch_regtile<1, 0>(grid, block, shm, s.sc, a); break;
-  }
+  hipLaunchKernelGGL(fn, grid, block, shm, s.sc, a);
   HIPC(hipGetLastError());
   hipLaunchKernelGGL(lbm::lbm_fold_steps, dim3(cdiv(nsteps, lbm::kBlock / 64)), dim3(lbm::kBlock), 0, s.sc,
                      c->rpartials, ntiles, nsteps, s.sums, c->rabort, s.err_host + 1);
@@ -1816,10 +1767,9 @@ int run_regtile(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
     }
   }
   if (s.err_host[1] != 0) {
-    c->resident_broken = true;
     HIPC(hipMemsetAsync(c->rabort, 0, 64, s.sc));
     HIPC(hipStreamSynchronize(s.sc));
-    if (getenv("LBM_VERBOSE")) fprintf(stderr, "lbm: the register-tile kernel gave up (a tile was not scheduled); using the streaming kernels\n");
+    resident_give_up(c, "a tile waited 1 s for a neighbour: not every tile was running at once");
     return LBM_OK;
   }
   c->cur ^= 1;
@@ -1884,6 +1834,7 @@ int run_p2p(lbm_ctx* c, int nsteps, float* av_vels) {
   int rc;
   for (auto& s : c->slabs)
     if ((rc = ensure_sums(s, nsteps))) return rc;
+  if (p2p_march_on(c) && nsteps >= slab_K(c) && (rc = check_march_partials(c, true))) return rc;   // (before anything is queued)
 
   auto push = [&](Slab& s, const float* lat, uint32_t seq, bool do_push) -> int {
     const int grid = do_push ? push_grid : 1;
@@ -2049,19 +2000,22 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
   const float a1 = c->p.density * c->p.accel / 9.f;   // d2q9-bgk.c:230-231
   const float a2 = c->p.density * c->p.accel / 36.f;
   if (c->exchange == LBM_EXCHANGE_P2P) return run_p2p(c, nsteps, av_vels);
-  if (c->exchange == 0 && c->slabs.size() == 1 && c->engine == 2 && c->rplan.tx > 0 && !c->resident_broken) {
-    bool done = false;
-    int rr = run_resident(c, nsteps, av_vels, &done);
-    if (rr) return rr;
-    if (done) { c->engine_last = 2; return LBM_OK; }
-  }
-  if (c->exchange == 0 && c->slabs.size() == 1 && (c->engine == 3 || c->engine == 0) && c->tplan.ty > 0 && !c->resident_broken) {
+  if (c->exchange == 0 && c->slabs.size() == 1 && (c->engine == 3 || c->engine == 0) && c->tplan.ty > 0 && !c->resident_broken &&
+      (c->variant & 8) == 0) {
     bool done = false;
     int rr = run_regtile(c, nsteps, av_vels, &done);
+    if (rr && c->engine == 0) {
+      // automatic engine: a set-up or launch failure of the resident kernel (LDS attribute refused, tiles not all
+      // resident, allocation failed) is not the caller's problem -- the source lattice is untouched, the streaming kernels run
+      (void)hipGetLastError();
+      resident_give_up(c, lbm_last_error());
+      rr = LBM_OK;
+    }
     if (rr) return rr;
     if (done) { c->engine_last = 3; return LBM_OK; }
   }
-  if (c->engine >= 2) return fail(LBM_EINVAL, "the resident kernel gave up on this device, or this lattice has no resident tiling (engine = %d)", c->engine);
+  if (c->engine >= 2) return fail(LBM_EINVAL, "the resident kernel cannot run here (%s), or this lattice has no resident tiling (engine = %d)",
+                                  c->resident_why[0] ? c->resident_why : "no tiling", c->engine);
   c->engine_last = 1;
   const bool ex = c->exchange != 0;
   const bool pairs = t2_eligible(c) && nsteps >= 2;
@@ -2070,8 +2024,10 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
   for (auto& s : c->slabs)
     if ((rc = ensure_sums(s, nsteps))) return rc;
 
-  // ---- prologue: accelerate phase of the first step
   const bool slabs_march = ex && march_slabs_on(c) && nsteps >= slab_K(c);
+  if ((slabs_march || nsteps >= c->time_block) && (rc = check_march_partials(c, slabs_march))) return rc;   // (before anything is queued)
+
+  // ---- prologue: accelerate phase of the first step
   for (auto& s : c->slabs) {
     HIPC(hipSetDevice(s.dev));
     if (s.accel_row >= 0) {
@@ -2316,7 +2272,8 @@ extern "C" int lbm_set_option(lbm_ctx* c, const char* key, long value) {
   }
   if (!strcmp(key, "march_rows")) {
     if (value < 1 || value > c->p.ny) return fail(LBM_EINVAL, "march_rows must be in [1, ny]");
-    c->march_rows = (int)value;
+    { const int was = c->march_rows; c->march_rows = (int)value;
+      if (check_march_partials(c, c->exchange != 0 && c->exchange != LBM_EXCHANGE_P2P && march_slabs_on(c))) { c->march_rows = was; return LBM_EINVAL; } }
     return LBM_OK;
   }
   if (!strcmp(key, "march_kernel")) {
@@ -2326,7 +2283,8 @@ extern "C" int lbm_set_option(lbm_ctx* c, const char* key, long value) {
   }
   if (!strcmp(key, "wave_rows")) {
     if (value < 1 || value > c->p.ny) return fail(LBM_EINVAL, "wave_rows must be in [1, ny]");
-    c->wave_rows = (int)value;
+    { const int was = c->wave_rows; c->wave_rows = (int)value;
+      if (check_march_partials(c, c->exchange != 0 && (p2p_march_on(c) || (c->exchange != LBM_EXCHANGE_P2P && march_slabs_on(c))))) { c->wave_rows = was; return LBM_EINVAL; } }
     return LBM_OK;
   }
   if (!strcmp(key, "time_block")) {
@@ -2337,12 +2295,12 @@ extern "C" int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     return LBM_OK;
   }
   if (!strcmp(key, "engine")) {
-    if (value < 0 || value > 3) return fail(LBM_EINVAL, "engine must be 0 (auto), 1 (streaming kernels), 2 (resident in LDS) or 3 (resident in registers)");
-    if ((value == 2 && (c->exchange != 0 || c->slabs.size() != 1 || c->rplan.tx == 0)) ||
-        (value == 3 && (c->exchange != 0 || c->slabs.size() != 1 || c->tplan.ty == 0)))
-      return fail(LBM_EINVAL, "the resident kernels need a lattice alone on its GPU that tiles onto the CUs");
+    if (value != 0 && value != 1 && value != 3)
+      return fail(LBM_EINVAL, "engine must be 0 (auto), 1 (streaming kernels) or 3 (resident in registers); 2, the LDS-resident engine, was removed");
+    if (value == 3 && (c->exchange != 0 || c->slabs.size() != 1 || c->tplan.ty == 0))
+      return fail(LBM_EINVAL, "the resident kernel needs a lattice alone on its GPU that tiles onto the CUs");
     c->engine = (int)value;
-    if (value >= 2) c->resident_broken = false;
+    if (value == 3) { c->resident_broken = false; c->resident_why[0] = 0; if (c->tplan.bpc < 0) c->tplan.bpc = 0; }
     return LBM_OK;
   }
   if (!strcmp(key, "regtile")) {   // rows per tile * 10 + rows per wave
@@ -2353,17 +2311,9 @@ extern "C" int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     regtile_set(c, ty, r);
     return LBM_OK;
   }
-  if (!strcmp(key, "resident_tile")) {   // tx * 100000 + ty * 10 + cells per thread
-    const int tx = (int)(value / 100000), ty = (int)((value / 10) % 10000), v = (int)(value % 10);
-    if (c->exchange != 0 || c->slabs.size() != 1 || !resident_tile_ok(c, tx, ty, v))
-      return fail(LBM_EINVAL, "resident tile %d x %d with %d cells per thread does not fit this lattice / device", tx, ty, v);
-    resident_free(c);
-    resident_set_plan(c, tx, ty, v);
-    return LBM_OK;
-  }
   if (!strcmp(key, "kernel_variant")) {
-    if (value < 0 || value > 7) return fail(LBM_EINVAL, "kernel_variant must be in [0, 7]");
-    c->variant = value;
+    if (value < 0 || value > 15) return fail(LBM_EINVAL, "kernel_variant must be in [0, 15]");
+    c->variant = value;      // (bit 3: the one-step kernel with the reference's speed sum; see t2_eligible / march_eligible / lbm_run)
     return LBM_OK;
   }
   return fail(LBM_EINVAL, "unknown option %s", key);
@@ -2389,10 +2339,11 @@ extern "C" int lbm_get_info(const lbm_ctx* c, const char* key, double* value) {
   if (!strcmp(key, "engine_last")) { *value = c->engine_last; return LBM_OK; }
   if (!strcmp(key, "engine_next")) {   // what the next lbm_run will try first
     *value = (c->exchange == 0 && c->slabs.size() == 1 && !c->resident_broken)
-                 ? ((c->engine == 2 && c->rplan.tx > 0) ? 2 : ((c->engine == 3 || c->engine == 0) && c->tplan.ty > 0) ? 3 : 1) : 1;
+                 ? (((c->engine == 3 || c->engine == 0) && c->tplan.ty > 0 && (c->variant & 8) == 0) ? 3 : 1) : 1;
     return LBM_OK;
   }
-  if (!strcmp(key, "resident_tile")) { *value = c->rplan.tx * 100000.0 + c->rplan.ty * 10.0 + c->rplan.v; return LBM_OK; }
+  if (!strcmp(key, "resident_fallback")) { *value = c->resident_broken ? 1 : 0; return LBM_OK; }   // 1: the resident kernel could not run here
+  if (!strcmp(key, "regtile_blocks_per_cu")) { *value = c->tplan.bpc; return LBM_OK; }              // occupancy answer (0: not asked yet)
   if (!strcmp(key, "compute_units")) { *value = c->ncu; return LBM_OK; }
   if (!strcmp(key, "regtile")) { *value = c->tplan.ty * 10.0 + c->tplan.r; return LBM_OK; }
   if (!strcmp(key, "exchange")) { *value = c->exchange; return LBM_OK; }

@@ -93,6 +93,10 @@ constexpr int kNtStore = 2;    // nontemporal stores of the destination lattice
 constexpr int kNtLoad = 4;     // nontemporal loads of the source lattice
 constexpr int kBenchNoMath = 8;        // tools/kbench only: pull + store, no collision (wrong results)
 constexpr int kBenchAlignedOnly = 16;  // tools/kbench only: unshifted loads everywhere (wrong results)
+constexpr int kSpeedFromStored = 32;   // the step's average speed re-summed from the post-collision populations, the
+                                       // reference's own form (d2q9-bgk.c:1103-1130); lbm_sweep only (option
+                                       // kernel_variant bit 3): the form every kernel used until round 2, kept so that
+                                       // a discrepancy in av_vels can be bisected against it
 
 // (not FAST: correctly rounded, by the short sequences of lbm_exact_math.hip.h wherever they are proven)
 template <bool FAST> __device__ __forceinline__ float recip(float x) {
@@ -113,7 +117,7 @@ template <bool FAST> __device__ __forceinline__ float root(float x) {
 // what the optimiser happens to fuse in a given instantiation: all kernels built from it
 // (1, 2 or 4 cells per thread, one or two steps per pass, any slab decomposition) produce
 // bit-identical lattices.
-template <bool FAST, bool SPARSE = false>
+template <bool FAST, bool SPARSE = false, bool STORED = false>
 __device__ __forceinline__ float collide_cell(float (&p)[9], bool is_blocked, float omega) {
 #pragma clang fp contract(off)
   const float w0 = 4.f / 9.f, w1 = 1.f / 9.f, w2 = 1.f / 36.f;
@@ -147,7 +151,19 @@ __device__ __forceinline__ float collide_cell(float (&p)[9], bool is_blocked, fl
   // float sums (a few 1e-9 absolute per cell, random in sign: parts in 1e8 of a step's average, against the 1 % of
   // the reference's checker and the 2e-6 the tests hold it to).  Recomputing it from t[] cost 24 of the ~110
   // instructions of this function, in kernels that are bound by exactly those (lbm_regtile, lbm_wave).
-  const float speed = root<FAST>(usq);
+  // STORED: the reference's form -- density and velocity re-summed from the values about to be stored.
+  float speed;
+  if constexpr (STORED) {
+    float rho2 = t[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) rho2 += t[k];
+    const float inv2 = recip<FAST>(rho2);
+    const float vx = (t[1] + t[5] + t[8] - (t[3] + t[6] + t[7])) * inv2;
+    const float vy = (t[2] + t[5] + t[6] - (t[4] + t[7] + t[8])) * inv2;
+    speed = root<FAST>(__builtin_fmaf(vx, vx, vy * vy));
+  } else {
+    speed = root<FAST>(usq);
+  }
   // blocked cell: mirrored pulled values instead, no contribution.  SPARSE: most wavefronts hold no blocked cell at all
   // (0.5 % of the shipped 1024^2 deck is blocked) and skip the ten selects behind one wave-uniform branch.
   if constexpr (SPARSE) {
@@ -337,7 +353,7 @@ __global__ __launch_bounds__(kBlock) void lbm_sweep(const SweepArgs a) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) p[k] = q[k][v];
       if constexpr ((MODE & kBenchNoMath) == 0) {
-        local += collide_cell<FAST>(p, blk[v], a.omega);
+        local += collide_cell<FAST, false, (MODE & kSpeedFromStored) != 0>(p, blk[v], a.omega);
         if (do_accel) accelerate_cell(p, blk[v], a.a1, a.a2);
       } else {
         local += blk[v] ? 0.f : p[0];

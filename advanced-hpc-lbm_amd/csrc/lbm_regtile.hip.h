@@ -1,6 +1,6 @@
 // lbm_regtile.hip.h -- the whole step loop in ONE launch with the lattice resident in REGISTERS
-// (second form of the resident engine; the first, lbm_resident.hip.h, keeps tiles in LDS and spends its
-// time on 770 eight-byte stores per tile and step behind __syncthreads' vmcnt(0)).
+// (the first form of this engine kept the tiles in LDS and spent its time on 770 eight-byte stores per tile and
+// step behind __syncthreads' vmcnt(0); it was removed in round 3).
 //
 // One block per CU holds a tile of 64 columns x (NW x R) rows: wave w owns rows w R .. w R + R - 1, a lane
 // owns one column of them, 9 R registers.  One step of one wave (reference step:
@@ -35,7 +35,8 @@
 // The update is in place, with three saved registers (the old planes 2,5,6 -- going down: 4,7,8 -- of the
 // row just overwritten).  Mailbox of a tile, per parity: Sin / Nin [64 columns] (from the tile below /
 // above), Win / Ein [TY + 2 rows] (rows -1 .. TY: the two extra rows are the diagonal tiles' corner rows).
-// Two parities suffice for the reason given in lbm_resident.hip.h: the thread that consumes a granule owns
+// Two parities suffice: a tile sends state s+1 of a row only after pulling state s of the neighbouring rows from ALL the
+// tiles that row touches, and a neighbour sent ITS state s only after it had pulled this tile's state s-1 -- the thread that consumes a granule owns
 // the cell that produces the opposite one (a row's granule feeds rows rho-1, rho, rho+1 of the neighbour,
 // and the row is not recomputed before all three have been).
 // Every wait is bounded and watches a global abort word; a run that gives up leaves the source lattice
@@ -43,9 +44,28 @@
 #pragma once
 #include <type_traits>
 #include "lbm_kernels.hip.h"
-#include "lbm_resident.hip.h"   // gu32, kResidentTimeoutTicks, lbm_fold_steps
 
 namespace lbm {
+
+constexpr long long kResidentTimeoutTicks = 100000000LL;       // a wait for mail gives up after 1 s of the 100 MHz wall clock
+// timing experiments only (wrong results): LBM_RESIDENT_DEBUG=1 never waits for a tag, 2 also sends nothing
+constexpr int kResDebugNoWait = 64, kResDebugNoSend = 128;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+// Per-step sums of a whole-run launch: partials[step][tile] -> sums[step] (double, fixed order), one wave per step; also
+// hands the kernel's abort word to the host.
+__global__ __launch_bounds__(kBlock) void lbm_fold_steps(const float* partials, int ntiles, int nsteps, double* sums,
+                                                         const uint32_t* abort_word, uint32_t* abort_out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && abort_out != nullptr) *abort_out = *abort_word;
+  const int step = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (step >= nsteps) return;
+  const int lane = threadIdx.x & 63;
+  const float* p = partials + (long)step * ntiles;
+  double s = 0.0;
+  for (int i = lane; i < ntiles; i += 64) s += (double)p[i];
+  s = wave_sum(s);
+  if (lane == 0) sums[step] = s;
+}
 
 struct RegTileArgs {
   const float* src; float* dst; long plane; int pitch, nx, ny;

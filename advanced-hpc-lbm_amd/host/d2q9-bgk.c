@@ -219,15 +219,25 @@ int main(int argc, char* argv[])
     /* what the step loop would move at the one-step kernel's 72 B per lattice update; the
     ** temporally blocked kernels move 38.9 (two steps per pass) or 19.4 B (four), so this figure can
     ** exceed the 8 TB/s of the pins: bench.py reports the fraction at the kernel's own bytes */
-    double tb = 1.0;
+    double tb = 1.0, wave = 0.0, engine = 1.0;
     lbm_get_info(ctx, "time_block_active", &tb);
-    double wave = 0.0;
     lbm_get_info(ctx, "march_kernel", &wave);
-    const double bytes = tb >= 4.0 ? (wave > 0.5 ? (36.0 * 64.0 / (64.0 - 2.0 * tb) + 36.0) / tb : 19.37) : tb >= 2.0 ? 38.88 : 72.0;
-    printf("Steps per pass:\t\t\t\t%d\n", (int)tb);
-    printf("HBM GB/s at %.1f B per update:\t\t%.1f\n", bytes, mlups * bytes / 1000.0);
-    printf("Fraction of HBM peak (8 TB/s x GPUs):\t%.4f\n", mlups * bytes / 1000.0 / (8000.0 * ngpus));
-    printf("Equivalent GB/s at 72 B per update:\t%.1f\n", mlups * 72.0 / 1000.0);
+    lbm_get_info(ctx, "engine_last", &engine);
+    if (engine > 2.5) {
+      /* lbm_regtile: the whole run was ONE launch with the lattice in registers -- HBM saw the lattice once in and
+      ** once out, whatever the number of steps, so a per-update HBM figure would describe nothing */
+      const double bytes = params.maxIters > 0 ? 72.0 / params.maxIters : 72.0;
+      printf("Kernel:					lbm_regtile (whole run in one launch, lattice resident in registers)\n");
+      printf("Steps per pass:				%d\n", params.maxIters);
+      printf("HBM bytes per update (lattice in + out / steps):	%.4f\n", bytes);
+    } else {
+      const double bytes = tb >= 4.0 ? (wave > 0.5 ? (36.0 * 64.0 / (64.0 - 2.0 * tb) + 36.0) / tb : 19.37) : tb >= 2.0 ? 38.88 : 72.0;
+      printf("Kernel:					%s\n", tb >= 4.0 ? (wave > 0.5 ? "lbm_wave" : "lbm_march") : tb >= 2.0 ? "lbm_sweep2" : "lbm_sweep");
+      printf("Steps per pass:				%d\n", (int)tb);
+      printf("HBM GB/s at %.1f B per update:		%.1f\n", bytes, mlups * bytes / 1000.0);
+      printf("Fraction of HBM peak (8 TB/s x GPUs):	%.4f\n", mlups * bytes / 1000.0 / (8000.0 * ngpus));
+    }
+    printf("Equivalent GB/s at 72 B per update:	%.1f\n", mlups * 72.0 / 1000.0);
   }
   write_values(&params, state4, obstacles, av_vels, !skip_final);
 

@@ -12,11 +12,16 @@ the synthetic 8192x8192 lattice of BASELINE.json is measured in the same run and
 under "also".  Inputs are resident in HBM before the timed region; exactly K steps are
 timed between barrier + torch.cuda.synchronize() pairs; the maximum over ranks is used.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against HBM: the bytes
-its blocking scheme must move per lattice update (72 for one step per pass, 38.9 for two, 19.4
-for four: kernel_of) x the updates one launch covers / the mean launch time measured with HIP
-events on the library's own compute stream; the rate priced at the one-step kernel's 72 B per
-update is reported beside it as equiv_72B_*.  `cpu_baseline` times the serial reference on this host
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against TWO roofs and names the
+one that binds it (`bound`: "hbm", "valu" or "latency"):
+  hbm   bytes that crossed the HBM interface per launch (rocprofv3 PMC passes, profiles/hbm_traffic.json;
+        where there is no pass for the kernel: the minimum its blocking scheme must move, kernel_of)
+        / the mean launch time measured live with HIP events on the library's compute stream / 8 TB/s;
+  valu  vector instructions issued per launch (SQ_INSTS_VALU, profiles/kernel_counters.json) / the same
+        launch time / the chip's issue rate (256 CUs x 4 SIMDs x one wave-instruction per 2 cycles x 2.4 GHz);
+`frac` is the larger of the two.  The temporally blocked kernels move far fewer than the one-step
+kernel's 72 B per update, so the rate priced at 72 B is reported beside it as
+equiv_72B_* and may exceed 1.  `cpu_baseline` times the serial reference on this host
 (oracle/_ref/d2q9-bgk, built from the reference's own source; else our port) on a bounded
 sample of the same deck.
 """
@@ -41,6 +46,9 @@ import advanced_hpc_lbm_amd as L  # noqa: E402
 MULTI = False            # set in main(): more than one rank, or --rehearse-multi on one GPU
 BYTES_PER_LUP = 72.0     # 9 float32 reads + 9 float32 writes
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+# vector issue roof: 256 CUs x 4 SIMDs, a SIMD issues one wave64 VALU instruction per 2 cycles (SIMD-32), 2.4 GHz
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 0.5 * 2.4e9
+FP32_PEAK_TFLOPS = 157.3  # = that rate x 64 lanes x 2 flop (every slot an FMA), same guide
 
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -177,12 +185,9 @@ def kernel_of(lat, tb):
       lbm_sweep2   two steps per pass, 64x16 tiles + ring  (36 x 66x18/(64x16) + 36) / 2 = 38.9
       lbm_march    four steps per pass, 224 of 256 columns (36 x 258/224 + 36) / 4       = 19.4
       lbm_wave<K>  K steps per pass, 64-2K of 64 columns   (36 x 64/(64-2K) + 36) / K    = 19.3 / 13.7 / 10.5 (K = 4 / 6 / 8)
-      lbm_regtile / lbm_resident  the whole run on chip (registers / LDS): one load and one store of the lattice per
-                   RUN; the figure reported is that, per step -- the kernel is bound by arithmetic and by the hand-off
-                   between neighbouring tiles, not by HBM, so its `frac` is small by design and `equiv_72B_*` is the
-                   number that compares it with the streaming kernels"""
-    if int(lat.info("engine_last")) == 2:
-        return "lbm_resident", None
+      lbm_regtile  the whole run on chip (registers): one load and one store of the lattice per RUN; the figure
+                   reported is that, per step -- the kernel is bound by arithmetic and by the hand-off between
+                   neighbouring tiles, not by HBM"""
     if int(lat.info("engine_last")) == 3:
         return "lbm_regtile", None
     if tb >= 4 and int(lat.info("march_kernel")) == 1:       # one wave per 64 columns, 64 - 2K delivered
@@ -230,6 +235,22 @@ def measure(name, world, rank, local_rank, steps, warmup):
     # goes non-finite; float32 rounding alone drifts ~2e-8 per step (tests/test_gpu_parity.py)
     mass_drift = abs(lat.total_density() - mass0) / mass0
     bitexact = None
+    if not MULTI:
+        # N = 1: replay warm-up + steps with the ONE-STEP kernel (lbm_sweep: the kernel pinned to the reference's own
+        # known answers) on a second lattice and compare the whole state bit for bit, av_vels to summation order
+        try:
+            mine = lat.read_state()
+            with L.Lattice(p, ob, nslabs=1, devices=[local_rank]) as plain:
+                plain.set_option("time_block", 1)
+                av_w = np.concatenate([plain.run(warmup), plain.run(steps)]) if warmup > 0 else plain.run(steps)
+                assert int(plain.info("engine_last")) == 1 and int(plain.info("time_block_active")) == 1
+                ref = plain.read_state()
+            bitexact = bool(np.array_equal(mine.view(np.uint32), ref.view(np.uint32)) and
+                            np.allclose(av, av_w[warmup:], rtol=2e-6, atol=0))
+            del mine, ref
+        except Exception as e:
+            bitexact = False
+            print(f"post-run check against the one-step kernel failed: {type(e).__name__}: {e}", file=sys.stderr)
     if MULTI:
         # every decomposition and transport is bit-identical to the undivided lattice by construction
         # and by test: check it on THIS machine for THIS run, all warmup + steps steps of it
@@ -250,7 +271,7 @@ def measure(name, world, rank, local_rank, steps, warmup):
     cells = p.nx * p.ny
     local_cells = p.nx * (r1 - r0)
     launches = steps // tb + (steps % tb) // 2 + (steps % tb) % 2 if tb >= 4 else steps // tb + steps % tb
-    if kernel in ("lbm_regtile", "lbm_resident"):
+    if kernel == "lbm_regtile":
         launches, tb = 1, steps                              # the whole run is one launch
     launch_s = gpu_ms * 1e-3 / launches                  # mean duration of one launch on this GPU
     lups_per_launch = local_cells * steps / launches
@@ -259,19 +280,44 @@ def measure(name, world, rank, local_rank, steps, warmup):
     achieved = min_bytes * lups_per_launch / launch_s / 1e9
     equiv72 = BYTES_PER_LUP * lups_per_launch / launch_s / 1e9
     traffic = lookup_traffic(name, world, kernel, steps)
+    valu = lookup_valu(name, world, kernel, steps)
+    # the two roofs (module docstring): bytes that crossed the HBM interface, vector instructions issued
+    hbm_bytes = traffic if traffic is not None else min_bytes * lups_per_launch
+    hbm_frac = hbm_bytes / launch_s / 1e9 / HBM_PEAK_GBS
+    valu_frac = None if valu is None else valu / launch_s / VALU_PEAK_WAVE_INSTS
+    family = kernel.split("<")[0]
+    if family == "lbm_regtile":
+        bound = "latency"        # neither roof: tile-to-tile hand-offs (BINDS)
+    elif valu_frac is not None and valu_frac > hbm_frac:
+        bound = "valu"
+    else:
+        bound = "hbm"
+    if valu_frac is not None and valu_frac >= hbm_frac:
+        top = {"achieved": round(valu_frac * FP32_PEAK_TFLOPS, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+               "frac": round(valu_frac, 4),
+               "achieved_is": "vector issue slots used, priced as FMAs (64 lanes x 2 flop per wave-instruction): SQ_INSTS_VALU per "
+                              "launch (profiles/kernel_counters.json) / this run's launch time"}
+    else:
+        top = {"achieved": round(hbm_bytes / launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4),
+               "achieved_is": "PMC bytes per launch (profiles/hbm_traffic.json) / this run's launch time" if traffic is not None
+                              else "the kernel's minimum bytes per update x updates per launch / this run's launch time"}
     return {
         "wall_us": {"timed_region": round(dt * 1e6, 1), "lbm_run_call": round(t_run * 1e6, 1),
                     "inside_library": round(lib_ms * 1e3, 1), "gpu_events": round(gpu_ms * 1e3, 1)},
         "mlups": cells * steps / dt / 1e6,
         "ms_per_step": dt * 1e3 / steps,
         "gpu_ms_per_step": gpu_ms / steps,
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": kernel, "steps_per_launch": tb, "what_binds_it": BINDS.get(kernel.split("<")[0], ""),
-                     # `achieved` prices a lattice update at the bytes THIS kernel's blocking must move
-                     # (kernel_of), so frac <= 1 by construction; the same rate priced at the one-step
-                     # kernel's 72 B per update is reported separately and may exceed 1
+        "roofline": {"bound": bound, **top, "traffic": traffic,
+                     "kernel": kernel, "steps_per_launch": tb, "what_binds_it": BINDS.get(family, ""),
+                     "hbm_frac": round(hbm_frac, 4),
+                     "valu_frac": None if valu_frac is None else round(valu_frac, 4),
+                     "valu_wave_insts_per_launch": valu,
+                     "valu_lane_insts_per_lattice_update": None if valu is None else round(valu * 64 / lups_per_launch, 1),
+                     # the model figure: the bytes THIS kernel's blocking must move per update (kernel_of) at this
+                     # run's rate; the same rate priced at the one-step kernel's 72 B per update is
+                     # reported separately and may exceed 1
                      "min_bytes_per_lattice_update": round(min_bytes, 3),
+                     "min_bytes_gbs": round(achieved, 1), "min_bytes_frac": round(achieved / HBM_PEAK_GBS, 4),
                      "lattice_updates_per_launch": lups_per_launch,
                      "launch_us": round(launch_s * 1e6, 3),
                      "equiv_72B_gbs": round(equiv72, 1), "equiv_72B_frac": round(equiv72 / HBM_PEAK_GBS, 4),
@@ -286,11 +332,11 @@ def measure(name, world, rank, local_rank, steps, warmup):
 
 # what the committed profiles say limits each kernel: the HBM fraction alone does not tell it
 BINDS = {
-    "lbm_regtile": "the lattice stays in registers and HBM is crossed twice per run, so the HBM fraction is ~0 by design; a step is "
-                   "four tile-to-tile hand-offs of ~2000 cycles (sc1 store, sc1 load) overlapped with ~1000 cycles of arithmetic "
-                   "per row (profiles/r02_sq_counters.json: waves wait 49 % of their cycles)",
-    "lbm_wave": "its arithmetic (151 lane-instructions per update at K = 8 with fill rows and undelivered lanes): HBM traffic is "
-                "10 B per update",
+    "lbm_regtile": "tile-to-tile hand-off latency: the lattice stays in registers (HBM is crossed twice per RUN), a step is a chain "
+                   "of sc1 store -> sc1 load hand-offs between neighbouring tiles overlapped with the rows' arithmetic; neither "
+                   "roof binds it (valu_frac and hbm_frac both reported)",
+    "lbm_wave": "vector issue: its arithmetic, fill rows and undelivered lanes included (valu_lane_insts_per_lattice_update); "
+                "HBM traffic is ~10 B per update",
     "lbm_march": "HBM: 19.3 B per update measured, ~0.64 of peak; the 18-stream access pattern alone tops out at ~5.9 TB/s nominal",
     "lbm_sweep2": "HBM: 38.9 B per update",
     "lbm_sweep": "HBM: 72 B per update",
@@ -309,6 +355,22 @@ def lookup_traffic(name, world, kernel, steps=0):
         if key == "lbm_regtile" and e:          # one launch per run: the lattice once, plus the tiles' mail per step
             return e["hbm_fixed_bytes_per_launch"] + steps * e["hbm_bytes_per_step"]
         return e.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def lookup_valu(name, world, kernel, steps=0):
+    """Vector wave-instructions per launch of `kernel` on workload `name` (SQ_INSTS_VALU of a committed rocprofv3
+    --pmc pass, profiles/kernel_counters.json), or None."""
+    path = os.path.join(ROOT, "profiles", "kernel_counters.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    try:
+        key = kernel.replace("<", "").replace(">", "") if kernel.startswith("lbm_wave") else kernel.split("<")[0]
+        e = json.load(open(path)).get(name, {}).get(key, {})
+        if key == "lbm_regtile" and e:
+            return e["valu_wave_insts_per_step"] * steps
+        return e.get("valu_wave_insts_per_launch")
     except Exception:
         return None
 
@@ -431,9 +493,10 @@ def main():
             "wall_us": head["wall_us"],      # the timed region, the lbm_run call in it, the library's own clock, the GPU's
             "results_finite": head["finite"],
             "mass_drift": float("%.3g" % head["mass_drift"]),
-            # N > 1: this run's slabs, all warmup + steps steps, against the undivided lattice on every rank
+            # N = 1: the timed lattice (warm-up + steps) against the one-step kernel's, whole state bit for bit;
+            # N > 1: this run's slabs against the undivided lattice on every rank
             "results_bitexact": head["bitexact"],
-            "halo_verified": head["bitexact"],
+            "halo_verified": head["bitexact"] if MULTI else None,
             "results_valid": bool(head["finite"] and head["mass_drift"] < 1e-7 * (args.steps + args.warmup) + 1e-6
                                   and head["bitexact"] is not False),
         }

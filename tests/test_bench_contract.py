@@ -29,16 +29,22 @@ def test_bench_line_single_gpu(gpu):
     assert "workload" in d["config"] and "1024x1024" in d["config"]["workload"] and "model" not in d["config"]
     assert abs(d["value"] - 1024 * 1024 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
     ro = d["roofline"]
-    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0
-    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
-    assert 0.0 < ro["frac"] <= 1.0                         # priced at the kernel's own minimum bytes: a real fraction
-    assert ro["kernel"] == "lbm_regtile" and ro["steps_per_launch"] == 400        # the whole run in one launch, lattice in registers
-    ratio = ro["equiv_72B_gbs"] / ro["achieved"]                         # (both rounded in the line: compare loosely)
-    assert ro["equiv_72B_frac"] > ro["frac"] and abs(ratio * ro["min_bytes_per_lattice_update"] / 72.0 - 1.0) < 0.05
+    # two roofs, the binding one named: lbm_regtile is bound by neither (hand-off latency between tiles); its HBM
+    # fraction is tiny by design (the lattice crosses HBM twice per run), its vector-issue fraction the larger one
+    assert ro["bound"] == "latency" and ro["kernel"] == "lbm_regtile" and ro["steps_per_launch"] == 400
+    assert ro["unit"] in ("GB/s", "TFLOP/s") and ro["peak"] == (8000.0 if ro["unit"] == "GB/s" else 157.3)
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 2e-3 and 0.0 < ro["frac"] <= 1.0
+    assert 0.0 < ro["hbm_frac"] <= 1.0 and (ro["valu_frac"] is None or 0.0 < ro["valu_frac"] <= 1.0)
+    assert abs(ro["frac"] - max(ro["hbm_frac"], ro["valu_frac"] or 0.0)) < 2e-3
+    assert ro["equiv_72B_frac"] > ro["min_bytes_frac"]
+    assert abs(ro["equiv_72B_gbs"] / ro["min_bytes_gbs"] * ro["min_bytes_per_lattice_update"] / 72.0 - 1.0) < 0.05
     assert ro["traffic"] is None or ro["traffic"] > 0
     big = d["also"]["8192x8192"]["roofline"]
-    assert big["kernel"] == "lbm_wave<8>" and big["steps_per_launch"] == 8 and 0.0 < big["frac"] <= 1.0   # (the default from 3 chunks per wave slot)
-    assert d["gpu_ms_per_step"] <= d["ms_per_step"] and d["results_bitexact"] is None
+    assert big["kernel"].startswith("lbm_wave") and big["steps_per_launch"] in (6, 8) and 0.0 < big["frac"] <= 1.0
+    assert big["bound"] in ("valu", "hbm") and abs(big["frac"] - max(big["hbm_frac"], big["valu_frac"] or 0.0)) < 2e-3
+    # N = 1: the timed lattice was replayed with the one-step kernel and compared bit for bit
+    assert d["gpu_ms_per_step"] <= d["ms_per_step"] and d["results_bitexact"] is True and d["results_valid"] is True
+    assert d["also"]["8192x8192"]["results_bitexact"] is True
     cb = d["cpu_baseline"]
     assert cb["unit"] == "MLUPS" and cb["cores"] == 1 and cb["kind"] in ("reference", "port") and cb["value"] > 1
     assert d["results_finite"] is True

@@ -652,7 +652,8 @@ def test_option_and_argument_errors(gpu):
     p = L.read_params(pf)
     ob = L.read_obstacles(of, p)
     with L.Lattice(p, ob) as lat:
-        for key, val in (("vector_width", 3), ("kernel_variant", 8), ("time_block", 3), ("no_such_option", 1)):
+        for key, val in (("vector_width", 3), ("kernel_variant", 16), ("time_block", 3), ("no_such_option", 1),
+                         ("engine", 2), ("wave_rows", 0), ("march_rows", 10 ** 6)):   # (engine 2, LDS-resident, was removed)
             with pytest.raises(L.LbmError):
                 lat.set_option(key, val)
         with pytest.raises(L.LbmError):
@@ -900,32 +901,6 @@ def test_marching_kernel_is_the_default_on_big_lattices_only(gpu):
         assert lat.info("time_block_active") == 1
 
 
-@pytest.mark.parametrize("tile,nx,ny,steps", [
-    ((16, 16, 1), 64, 64, [1]), ((16, 16, 1), 64, 64, [7, 4]), ((16, 16, 4), 64, 64, [9]), ((32, 32, 2), 64, 64, [9]),
-    ((64, 64, 4), 64, 64, [9]),                      # one tile: it is its own neighbour on all eight sides
-    (None, 128, 256, [12]), ((32, 16, 4), 96, 80, [10]), ((8, 5, 1), 96, 80, [10]), ((8, 12, 2), 40, 36, [10]),
-    (None, 1024, 1024, [21]),
-])
-def test_resident_kernel_equals_single_step_kernel(gpu, tile, nx, ny, steps):
-    """lbm_resident (engine 2: the whole run in one launch, tiles in LDS, tagged 8-byte granules between
-    neighbouring tiles through L2) against the one-step streaming kernel: bit-identical lattice."""
-    L = gpu
-    p, ob, cells = _random_case(L, nx, ny, 11)
-    with L.Lattice(p, ob, cells) as a:
-        a.set_option("time_block", 1)
-        av_a = np.concatenate([a.run(n) for n in steps])
-        st_a = a.read_state()
-    with L.Lattice(p, ob, cells) as b:
-        b.set_option("engine", 2)
-        if tile is not None:
-            b.set_option("resident_tile", tile[0] * 100000 + tile[1] * 10 + tile[2])
-        av_b = np.concatenate([b.run(n) for n in steps])
-        assert b.info("engine_last") == 2
-        st_b = b.read_state()
-    assert np.array_equal(st_a.view(np.uint32), st_b.view(np.uint32))
-    assert np.allclose(av_a, av_b, rtol=2e-6, atol=0)
-
-
 def test_cli_on_generated_deck(gpu, tmp_path):
     """tools/make_deck.py writes params + obstacle files the CLI reads (d2q9-bgk.c:2736-2762, 2844-2857):
     a 2048 x 2048 deck end to end (final_state.dat skipped), av_vels.dat against Lattice.run on the same map."""
@@ -1109,9 +1084,205 @@ def test_register_tile_kernel_that_cannot_finish_falls_back_to_the_streaming_ker
         av_b = b.run(9)
         waited = time.perf_counter() - t0
         assert b.info("engine_last") == 1 and 0.5 < waited < 10.0
+        assert b.info("resident_fallback") == 1                 # ... and the caller can tell (stderr says why, once)
         st_b = b.read_state()
         monkeypatch.delenv("LBM_REGTILE_FAULT")
         b.run(3)
         assert b.info("engine_last") == 1          # (it stays with the streaming kernels on this context)
     assert np.array_equal(st_a.view(np.uint32), st_b.view(np.uint32))
     assert np.allclose(av_a, av_b, rtol=2e-6, atol=0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Round 3: the kernels that used to be checked only against lbm_sweep, now against the ORACLE and the golden files
+# directly ("parity evidence"), and the advisor's regressions.
+
+@pytest.mark.parametrize("deck", ["128x256", "1024x1024"])
+@pytest.mark.parametrize("K", [6, 8])
+def test_wave_kernels_against_float_oracle(gpu, O, oracle, deck, K):
+    """lbm_wave<6> / lbm_wave<8> (the 8192^2 default) against the strict float oracle itself, 50 steps from the rest
+    equilibrium of a shipped deck (128x256: rows 0 / 255 open, the y-wrap is live; 1024x1024: the headline deck):
+    50 = six / eight groups of K plus a remainder through lbm_sweep2.  Same bars as the one-step kernel's test."""
+    L = gpu
+    pf, of = deck_paths(deck)
+    p = L.read_params(pf)
+    ob = L.read_obstacles(of, p)
+    op = O.read_params(pf)
+    cells = oracle.init_cells(op, np.float32)
+    av_o = oracle.run(op, cells, ob, 50)
+    for variant in (0, 1, 3):
+        with L.Lattice(p, ob) as lat:
+            lat.set_option("march_kernel", 1)
+            lat.set_option("time_block", K)
+            lat.set_option("kernel_variant", variant)
+            assert lat.info("time_block_active") == K and lat.info("march_kernel") == 1
+            av = lat.run(50)
+            assert lat.info("engine_last") == 1
+            st = lat.read_state()
+        assert np.abs(st - cells).max() <= 5e-5 * np.abs(cells).max(), (K, variant)
+        assert np.allclose(av, av_o, rtol=1e-4, atol=0), (K, variant)
+
+
+def test_full_run_against_golden_files_with_the_8192_default_kernel(gpu):
+    """The 1024x1024 deck's whole 20000-step run through lbm_wave<8> (engine 1, time_block 8: what runs by default at
+    8192^2) against the golden files, the reference checker's semantics (check/check.py:83-139)."""
+    import check_results as CR
+    L = gpu
+    pf, of = deck_paths("1024x1024")
+    p = L.read_params(pf)
+    ob = L.read_obstacles(of, p)
+    with L.Lattice(p, ob) as lat:
+        lat.set_option("engine", 1)
+        lat.set_option("march_kernel", 1)
+        lat.set_option("time_block", 8)
+        assert lat.info("time_block_active") == 8 and lat.info("march_kernel") == 1
+        av = lat.run(p.maxIters).astype(np.float64)
+        assert lat.info("engine_last") == 1
+        pressure = lat.final_state()[..., 3].astype(np.float64).ravel()
+    gold_av = np.loadtxt(os.path.join(GOLDEN, "1024x1024.av_vels.dat"), usecols=[1])
+    a = CR.worst_deviation(gold_av, av)
+    assert CR.passes(a, 1.0) and abs(a["percent"]) < 0.25, a
+    with np.load(os.path.join(GOLDEN, "1024x1024.final_state.pressure.f64.npz")) as z:
+        gold_p = z["pressure"].ravel()
+    f = CR.worst_deviation(gold_p, pressure)
+    assert CR.passes(f, 1.0) and abs(f["percent"]) < 0.25, f
+
+
+def test_full_size_default_kernel_equals_one_step_kernel(gpu):
+    """8192x8192, 19 steps (two groups of eight and a remainder): whatever runs by default there against the one-step
+    kernel lbm_sweep (the kernel pinned to the reference's known answers): the whole state, bit for bit."""
+    L = gpu
+    n = 8192
+    p = L.Param(n, n, 19, 10, 0.1, 0.01, 1.85)
+    ob = np.zeros((n, n), np.int32)
+    ob[0, :] = ob[-1, :] = 1
+    ob[:, 0] = ob[:, -1] = 1
+    ob[:, 2730] = 1
+    rng = np.random.default_rng(4321)
+    ob[rng.integers(1, n - 1, 60000), rng.integers(1, n - 1, 60000)] = 1
+    with L.Lattice(p, ob) as lat:
+        assert lat.info("time_block_active") >= 4          # a marching kernel
+        av_d = lat.run(19)
+        st_d = lat.read_state()
+    with L.Lattice(p, ob) as lat:
+        lat.set_option("time_block", 1)
+        av_1 = lat.run(19)
+        st_1 = lat.read_state()
+    assert np.array_equal(st_d.view(np.uint32), st_1.view(np.uint32))
+    assert np.allclose(av_d, av_1, rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("tile,nx,ny,steps", [
+    ((4, 4), 64, 8, 5), ((8, 4), 64, 8, 7), ((4, 2), 128, 16, 7), ((16, 1), 128, 16, 7), ((32, 4), 192, 96, 10),
+    ((8, 4), 256, 256, 9), ((32, 4), 1024, 1024, 9), ((64, 4), 1024, 1024, 9), (None, 256, 256, 12),
+])
+def test_register_tile_tilings_against_float_oracle(gpu, O, oracle, tile, nx, ny, steps):
+    """lbm_regtile, default and non-default tilings, against the strict float oracle on random lattices with 10 %
+    obstacles (not only against lbm_sweep): element-wise 2e-5, av_vels 2e-5."""
+    L = gpu
+    p, ob, cells = _random_case(L, nx, ny, 5)
+    op = O.OrcParam(nx, ny, steps, 10, 0.1, 0.01, 1.85)
+    ref = cells.copy()
+    av_o = oracle.run(op, ref, ob, steps)
+    with L.Lattice(p, ob, cells) as b:
+        if tile is not None:
+            b.set_option("regtile", tile[0] * 10 + tile[1])
+        b.set_option("engine", 3)
+        av = b.run(steps)
+        assert b.info("engine_last") == 3 and b.info("regtile_blocks_per_cu") >= 1 and b.info("resident_fallback") == 0
+        st = b.read_state()
+    assert np.all(np.abs(st - ref) <= 2e-5 * np.abs(ref) + 2e-6 * np.abs(ref).max())
+    assert np.allclose(av, av_o, rtol=2e-5, atol=0)
+
+
+@pytest.mark.parametrize("K", [4, 6, 8])
+@pytest.mark.parametrize("ny", [4, 8, 12, 15, 16, 17])
+def test_wave_kernel_on_short_lattices(gpu, K, ny):
+    """lbm_wave<K> applies the accelerate phase at two periodic images of row ny-2 per chunk; on a lattice
+    shorter than 2K rows a third image falls among the chunk's fill rows.  Such lattices must not march (ny < 2K), and
+    the ones that just do (ny >= 2K) must come out bit-identical to the one-step kernel."""
+    L = gpu
+    p, ob, cells = _random_case(L, 64, ny, 21)
+    with L.Lattice(p, ob, cells) as a:
+        a.set_option("time_block", 1)
+        av_a = a.run(3 * K + 1)
+        st_a = a.read_state()
+    with L.Lattice(p, ob, cells) as b:
+        b.set_option("march_kernel", 1)
+        b.set_option("time_block", K)
+        assert (b.info("time_block_active") == K) == (ny >= 2 * K), (K, ny, b.info("time_block_active"))
+        av_b = b.run(3 * K + 1)
+        st_b = b.read_state()
+    assert np.array_equal(st_a.view(np.uint32), st_b.view(np.uint32))
+    assert np.allclose(av_a, av_b, rtol=2e-6, atol=0)
+
+
+def test_chunk_heights_that_overflow_the_partial_sums_are_refused_when_set(gpu):
+    """a chunk height whose blocks do not fit the per-block partial sums used to fail inside lbm_run, after
+    the prologue had already applied the accelerate phase.  It is refused by lbm_set_option now, the option keeps its
+    value, and the lattice is untouched."""
+    L = gpu
+    p, ob, cells = _random_case(L, 1024, 512, 8)
+    with L.Lattice(p, ob, cells) as a:
+        a.set_option("time_block", 1)
+        a.run(8)
+        st_a = a.read_state()
+    with L.Lattice(p, ob, cells) as b:
+        b.set_option("march_kernel", 1)
+        b.set_option("time_block", 8)
+        rows = b.info("wave_rows")
+        with pytest.raises(L.LbmError, match="partial-sum"):
+            b.set_option("wave_rows", 1)
+        assert b.info("wave_rows") == rows
+        assert np.array_equal(b.read_state().view(np.uint32), cells.view(np.uint32))
+        b.run(8)
+        st_b = b.read_state()
+    assert np.array_equal(st_a.view(np.uint32), st_b.view(np.uint32))
+
+
+def test_register_tile_mailboxes_survive_a_change_of_tiling(gpu):
+    """mailbox tags only ever grow on a context -- a mailbox allocated anew (after a change of tiling) is
+    zeroed and valid for any tag, and a mailbox kept across runs never sees a tag twice.  Tilings alternate on one
+    context; the lattice stays bit-identical to the one-step kernel's."""
+    L = gpu
+    p, ob, cells = _random_case(L, 256, 256, 13)
+    with L.Lattice(p, ob, cells) as a:
+        a.set_option("time_block", 1)
+        a.run(24)
+        st_a = a.read_state()
+    with L.Lattice(p, ob, cells) as b:
+        for tile, n in (((4, 1), 5), ((8, 4), 5), ((4, 1), 3), ((16, 2), 4), ((8, 4), 7)):
+            b.set_option("regtile", tile[0] * 10 + tile[1])
+            b.set_option("engine", 3)
+            b.run(n)
+            assert b.info("engine_last") == 3
+        st_b = b.read_state()
+    assert np.array_equal(st_a.view(np.uint32), st_b.view(np.uint32))
+
+
+@pytest.mark.parametrize("deck", ["128x128", "1024x1024"])
+def test_reference_form_of_the_speed_sum_is_selectable(gpu, O, oracle, deck):
+    """kernel_variant bit 3 re-sums the cell's speed from the stored populations, the
+    reference's own form (d2q9-bgk.c:1103-1130), in the one-step kernel.  The lattice is the same bit for bit either
+    way; with the bit set av_vels follow the strict float oracle to 2e-6 over 50 steps (the default form: 1e-4 bar)."""
+    L = gpu
+    pf, of = deck_paths(deck)
+    p = L.read_params(pf)
+    ob = L.read_obstacles(of, p)
+    op = O.read_params(pf)
+    cells = oracle.init_cells(op, np.float32)
+    av_o = oracle.run(op, cells, ob, 50)
+    with L.Lattice(p, ob) as lat:
+        lat.set_option("time_block", 1)
+        lat.set_option("kernel_variant", 0)
+        lat.run(50)
+        st_default = lat.read_state()
+    for variant in (8, 9):
+        with L.Lattice(p, ob) as lat:
+            lat.set_option("kernel_variant", variant)
+            assert lat.info("time_block_active") == 1 and lat.info("engine_next") == 1   # the bit selects the one-step kernel
+            av = lat.run(50)
+            st = lat.read_state()
+        assert np.allclose(av, av_o, rtol=2e-6, atol=0), variant
+        if variant == 8:
+            assert np.array_equal(st.view(np.uint32), st_default.view(np.uint32))
