@@ -149,6 +149,16 @@ struct Slab {
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
   hipEvent_t ev_march[2] = {nullptr, nullptr};   // "marching launch n of this slab has finished" (by launch parity)
   int accel_row = -1;          // local index of global row ny-2, or -1
+  // Ghost bands (marching kernels under the RCCL transport): the K rows below / above the slab as the neighbours hold
+  // them, received once per K steps.  band_*[i] accompanies lat[i]: [9 planes][K rows][pitch]; the obstacle bytes of
+  // kBandRows rows either side are uploaded at create (row i of band_blk_s = global row row0 - kBandRows + i).
+  float* band_s[2] = {nullptr, nullptr};
+  float* band_n[2] = {nullptr, nullptr};
+  float* band_send_s = nullptr;    // own bottom / top K rows, packed for the neighbours
+  float* band_send_n = nullptr;
+  uint8_t* band_blk_s = nullptr;
+  uint8_t* band_blk_n = nullptr;
+  int band_K = 0;              // K the float bands are sized for (0: none yet)
   rccl::comm_t comm = nullptr;
   // peer-to-peer halos (LBM_EXCHANGE_P2P): one uncached block holds ghost_s[2], ghost_n[2] and the
   // two flags the neighbours raise; the neighbours' blocks are mapped here (peer access or hipIpc)
@@ -188,6 +198,7 @@ struct lbm_ctx {
                                // register pipeline, K = 4 / 6 / 8, any width from 64 up), -1 = lbm_march where it can run
                                // (269 GLUPS at 8192^2 against 262 for lbm_wave<8>), lbm_wave elsewhere
   int wave_rows = 0;           // rows per chunk of lbm_wave; 0 = not chosen yet
+  int wave_cols = 1;           // columns per lane of lbm_wave: 1 (a wave delivers 64 - 2K columns) or 2 (128 - 2K; K = 6, 8; even widths from 128)
   int wave_capacity = 0;       // waves of lbm_wave<time_block> the device holds at once (occupancy query)
   uint32_t seq = 0;            // peer-to-peer: sequence number of the last launch group (same on all slabs)
   bool p2p_connected = false;
@@ -219,6 +230,8 @@ struct lbm_ctx {
 
 // tile of the two-step kernel
 constexpr int kT2X = 64, kT2Y = 16;
+// rows of obstacle bytes kept either side of a slab for the ghost bands of the marching kernels (the largest K)
+constexpr int kBandRows = 8;
 
 namespace {
 
@@ -246,6 +259,16 @@ void slab_free_halos(Slab& s) {
   if (s.blocked_gs) (void)hipFree(s.blocked_gs);
   if (s.blocked_gn) (void)hipFree(s.blocked_gn);
   s.blocked_gs = s.blocked_gn = nullptr;
+  for (int i = 0; i < 2; ++i) {
+    if (s.band_s[i]) (void)hipFree(s.band_s[i]);
+    if (s.band_n[i]) (void)hipFree(s.band_n[i]);
+    s.band_s[i] = s.band_n[i] = nullptr;
+  }
+  if (s.band_send_s) (void)hipFree(s.band_send_s);
+  if (s.band_send_n) (void)hipFree(s.band_send_n);
+  if (s.band_blk_s) (void)hipFree(s.band_blk_s);
+  if (s.band_blk_n) (void)hipFree(s.band_blk_n);
+  s.band_send_s = s.band_send_n = nullptr; s.band_blk_s = s.band_blk_n = nullptr; s.band_K = 0;
   for (int side = 0; side < 2; ++side)
     for (int i = 0; i < 3; ++i) {
       if (s.nb_ipc[side][i] && (side == 0 || s.nb_ipc[1][i] != s.nb_ipc[0][i])) (void)hipIpcCloseMemHandle(s.nb_ipc[side][i]);
@@ -296,6 +319,8 @@ int slab_alloc_halos(lbm_ctx* c, Slab& s) {
     const size_t hb = sizeof(float) * lbm::kHaloSlots * (size_t)nx;
     HIPC(hipMalloc((void**)&s.blocked_gs, (size_t)nx));
     HIPC(hipMalloc((void**)&s.blocked_gn, (size_t)nx));
+    HIPC(hipMalloc((void**)&s.band_blk_s, (size_t)kBandRows * s.pitch));
+    HIPC(hipMalloc((void**)&s.band_blk_n, (size_t)kBandRows * s.pitch));
     for (int i = 0; i < 2; ++i) {
       HIPC(hipMalloc((void**)&s.ghost_s[i], hb));
       HIPC(hipMalloc((void**)&s.ghost_n[i], hb));
@@ -358,6 +383,20 @@ int upload_ghost_masks(lbm_ctx* c, Slab& s, const int* obstacles) {
   for (int x = 0; x < nx; ++x) { gs[x] = obstacles[(long)rs * nx + x] ? 1 : 0; gn[x] = obstacles[(long)rn * nx + x] ? 1 : 0; }
   HIPC(hipMemcpyAsync(s.blocked_gs, gs.data(), nx, hipMemcpyHostToDevice, s.sc));
   HIPC(hipMemcpyAsync(s.blocked_gn, gn.data(), nx, hipMemcpyHostToDevice, s.sc));
+  std::vector<uint8_t> bs, bn;
+  if (s.band_blk_s) {
+    // the kBandRows rows below and above the slab (periodic in the global lattice), for the ghost bands
+    bs.assign((size_t)kBandRows * s.pitch, 0); bn.assign((size_t)kBandRows * s.pitch, 0);
+    for (int i = 0; i < kBandRows; ++i) {
+      const int gs_row = ((s.row0 - kBandRows + i) % ny + ny) % ny, gn_row = (s.row0 + s.nyl + i) % ny;
+      for (int x = 0; x < nx; ++x) {
+        bs[(size_t)i * s.pitch + x] = obstacles[(long)gs_row * nx + x] ? 1 : 0;
+        bn[(size_t)i * s.pitch + x] = obstacles[(long)gn_row * nx + x] ? 1 : 0;
+      }
+    }
+    HIPC(hipMemcpyAsync(s.band_blk_s, bs.data(), bs.size(), hipMemcpyHostToDevice, s.sc));
+    HIPC(hipMemcpyAsync(s.band_blk_n, bn.data(), bn.size(), hipMemcpyHostToDevice, s.sc));
+  }
   HIPC(hipStreamSynchronize(s.sc));
   return LBM_OK;
 }
@@ -443,6 +482,7 @@ void pick_defaults(lbm_ctx* c) {
   if ((e = getenv("LBM_TIME_BLOCK"))) { const int v = atoi(e); c->time_block = (v == 8 || v == 6 || v == 4 || v == 2) ? v : 1; }
   if ((e = getenv("LBM_MARCH_KERNEL"))) c->march_kernel = atoi(e) == 0 ? 0 : atoi(e) == 1 ? 1 : -1;
   if ((e = getenv("LBM_WAVE_ROWS")) && atoi(e) > 0) c->wave_rows = std::min(atoi(e), c->p.ny);
+  if ((e = getenv("LBM_WAVE_COLS"))) c->wave_cols = atoi(e) == 2 ? 2 : 1;
   if ((e = getenv("LBM_MARCH_ROWS")) && atoi(e) > 0) c->march_rows = std::min(atoi(e), c->p.ny);
   if ((e = getenv("LBM_T2_THREADS"))) { const int t = atoi(e); if (t == 256 || t == 512 || t == 1024) c->t2_threads = t; }
 }
@@ -458,6 +498,10 @@ bool t2_eligible(const lbm_ctx* c) {
 
 // Steps per pass of the marching kernel (lbm_march.hip.h).
 constexpr int kMarchK = 4;
+// lbm_wave: columns per lane actually used (two need an even width of at least one 128-column strip and K = 6 or 8),
+// and the columns a wave delivers
+inline int wave_C(const lbm_ctx* c, int K) { return (c->wave_cols == 2 && (K == 6 || K == 8) && c->p.nx % 2 == 0 && c->p.nx >= 128) ? 2 : 1; }
+inline int wave_out_cols(const lbm_ctx* c, int K) { return 64 * wave_C(c, K) - 2 * K; }
 
 // The marching kernel runs on a lattice alone on its GPU (periodic wrap inside the kernel); its row
 // fetches are 16-byte LDS-DMA pieces, so columns must come in fours, and a strip is 256 columns wide.
@@ -689,12 +733,14 @@ int ensure_sums(Slab& s, int nsteps) {
 }
 
 bool plan_regtile(lbm_ctx* c);    // resident engine, below
+typedef void (*wave_fn)(const lbm::WaveArgs);
+wave_fn wave_kernel(int K, bool slab, int C, int flavour);   // the lbm_wave instantiations, below
 bool march_slabs_setup(lbm_ctx* c);   // marching kernel across slabs, below
-template <int K> int wave_blocks_per_cu();   // occupancy of lbm_wave<K>, below
+int wave_blocks_per_cu(int K, int C);        // occupancy of lbm_wave<K, ., ., C>, below
 bool p2p_march_pays(const lbm_ctx* c);
 bool slab_wave_pays(const lbm_ctx* c, int rows);
-int slab_wave_rows(const lbm_ctx* c, int ny_rows);
-double slab_wave_efficiency(const lbm_ctx* c, int ny_rows, int h);
+int slab_wave_rows(const lbm_ctx* c, int ny_rows, int K = 8, int extra_waves = 0);
+double slab_wave_efficiency(const lbm_ctx* c, int ny_rows, int h, int K = 8, int extra_waves = 0);
 int march_rows_for(const lbm_ctx* c, int ny_rows);
 
 int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
@@ -727,6 +773,11 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
       // (a function of the lattice and the number of slabs only: every rank decides alike)
       if (c->p.nx % 4 == 0 && c->p.nx >= lbm::MarchCfg<kMarchK>::W && c->p.ny / c->nranks >= 4 * kMarchK && p2p_march_pays(c)) c->time_block = 4;
       if (c->time_block == 4 && c->march_kernel != 0 && !getenv("LBM_MARCH_KERNEL") && slab_wave_pays(c, c->p.ny / c->nranks)) c->time_block = 8;
+    } else
+    if (!getenv("LBM_TIME_BLOCK") && c->time_block == 2 && exchanging && c->exchange == LBM_EXCHANGE_RCCL) {
+      // RCCL halos (one process per GPU, or one process with a slab per GPU): lbm_wave<8> with ghost bands -- K rows of all
+      // nine planes per direction per K steps -- where the smallest slab fills the chip's wave slots (every rank decides alike)
+      if (c->march_kernel != 0 && slab_wave_pays(c, c->p.ny / c->nranks)) c->time_block = 8;
     } else
     if (!getenv("LBM_TIME_BLOCK") && c->time_block == 2 && exchanging) {
       // slabs of one process: lbm_march with the neighbours' rows read in place, where every slab fills the chip
@@ -1281,8 +1332,8 @@ bool march_slabs_setup(lbm_ctx* c) {
   if (c->march_slabs >= 0) return c->march_slabs == 1;
   c->march_slabs = 0;
   if (c->rank_mode || c->exchange == 0 || c->exchange == LBM_EXCHANGE_RCCL) return false;
-  const int K = (c->time_block == 8) ? 8 : kMarchK;
-  if (K == 8 ? c->p.nx < 64 : (c->p.nx % 4 != 0 || c->p.nx < lbm::MarchCfg<kMarchK>::W)) return false;
+  const int K = (c->time_block == 8 || c->time_block == 6) ? c->time_block : kMarchK;
+  if (K != kMarchK ? c->p.nx < 64 : (c->p.nx % 4 != 0 || c->p.nx < lbm::MarchCfg<kMarchK>::W)) return false;
   const int ns = (int)c->slabs.size();
   for (auto& s : c->slabs)
     if (s.nyl < 4 * K || (double)s.nyl * s.pitch * 4.0 >= 4.0e9) return false;
@@ -1300,10 +1351,10 @@ bool march_slabs_setup(lbm_ctx* c) {
   c->march_slabs = 1;
   return true;
 }
-// Steps per marching pass of a context whose slabs trade rows: 8 = lbm_wave<8>, 4 = lbm_march, 0 = no marching.
+// Steps per marching pass of a context whose slabs trade rows: 8 / 6 = lbm_wave<8> / <6>, 4 = lbm_march, 0 = no marching.
 inline int slab_K(const lbm_ctx* c) {
   if (c->exchange == 0 || (c->variant & 8)) return 0;
-  if (c->time_block == 8) return (c->p.nx >= 64) ? 8 : 0;
+  if (c->time_block == 8 || c->time_block == 6) return (c->p.nx >= 64) ? c->time_block : 0;
   if (c->time_block == kMarchK) return (c->p.nx % 4 == 0 && c->p.nx >= lbm::MarchCfg<kMarchK>::W) ? kMarchK : 0;
   return 0;
 }
@@ -1323,33 +1374,39 @@ int march_rows_for(const lbm_ctx* c, int ny_rows) {
 }
 // Rows per chunk of lbm_wave<8> on a slab of ny_rows rows, and the share of the chip's wave-slot time that is useful
 // work with it: a chunk costs 2K fill iterations, and waves that do not fill the last round leave slots idle.
-int wave_slots(const lbm_ctx* c) { return std::max(c->ncu, 1) * std::max(wave_blocks_per_cu<8>(), 1) * (lbm::kWaveBlock / 64); }
+inline bool slab_is_wave(int K) { return K == 8 || K == 6; }
+// wave slots of the chip for lbm_wave<K> with the context's columns per lane
+int wave_slots(const lbm_ctx* c, int K = 8) { return std::max(c->ncu, 1) * std::max(wave_blocks_per_cu(K, wave_C(c, K)), 1) * (lbm::kWaveBlock / 64); }
 // The share of the chip's wave-slot time that is useful work with chunks of h rows: a chunk costs its 2K fill
 // iterations on top of its h, and the waves come in rounds of `slots`: up to three rounds a partial round costs a whole
 // one (4096^2: 118-row chunks = 0.98 rounds 285 GLUPS, 114-row chunks = 1.008 rounds 231; 5120^2: 91 rows = 1.99 rounds
 // 310, 87 rows = 2.06 rounds 282), beyond that the rounds blur into each other.  A single round, in which every wave
 // fills at the same time, runs ~0.87 of what this predicts, several rounds ~0.94 (371 GLUPS x this figure against the
 // measured rates of 2048^2 ... 8192^2 and of the 8192-wide slabs).
-double slab_wave_efficiency(const lbm_ctx* c, int ny_rows, int h) {
-  const long waves = (long)cdiv(c->p.nx, 64 - 16) * cdiv(ny_rows, h), slots = wave_slots(c);
+double slab_wave_efficiency(const lbm_ctx* c, int ny_rows, int h, int K, int extra_waves) {
+  const int nwc = cdiv(c->p.nx, wave_out_cols(c, K));
+  const long waves = (long)nwc * cdiv(ny_rows, h) + extra_waves, slots = wave_slots(c, K);
   const double r = (double)waves / slots;
   const double rounds = r <= 3.0 ? std::ceil(r) : r;
   const double shape = rounds <= 1.0 ? 0.87 : 0.94;
-  return shape * (double)cdiv(c->p.nx, 64 - 16) * ny_rows / (rounds * slots * (h + 16.0));
+  // (a level's fill rows are half empty on average: K of the 2K fill iterations' worth of work)
+  return shape * (double)nwc * ny_rows / (rounds * slots * (h + 2.0 * K));
 }
-int slab_wave_rows(const lbm_ctx* c, int ny_rows) {
+int slab_wave_rows(const lbm_ctx* c, int ny_rows, int K, int extra_waves) {
   if (c->wave_rows > 0) return std::min(c->wave_rows, ny_rows);
+  const int hmax = wave_C(c, K) == 2 ? 192 : 128;
   int best_h = std::min(ny_rows, 128);
   double best = -1.0;
-  for (int h = std::min(ny_rows, 32); h <= std::min(ny_rows, 128); ++h) {        // (beyond 128 rows the chunks get slower: measured)
-    const double e = slab_wave_efficiency(c, ny_rows, h);
+  for (int h = std::min(ny_rows, 32); h <= std::min(ny_rows, hmax); ++h) {        // (beyond 128 rows the one-column chunks get slower: measured)
+    const double e = slab_wave_efficiency(c, ny_rows, h, K, extra_waves);
     if (e > best + 1e-9) { best = e; best_h = h; }
   }
   return best_h;
 }
 // partial-sum slots (blocks) of one marching launch on a slab
 inline int march_slab_blocks(const lbm_ctx* c, const Slab& s) {
-  if (slab_K(c) == 8) return cdiv((long)cdiv(c->p.nx, 64 - 16) * cdiv(s.nyl, slab_wave_rows(c, s.nyl)), lbm::kWaveBlock / 64);
+  const int K = slab_K(c);
+  if (slab_is_wave(K)) return cdiv((long)cdiv(c->p.nx, wave_out_cols(c, K)) * cdiv(s.nyl, slab_wave_rows(c, s.nyl, K)), lbm::kWaveBlock / 64);
   return cdiv(c->p.nx, lbm::MarchCfg<kMarchK>::WOUT) * cdiv(s.nyl, march_rows_for(c, s.nyl));
 }
 
@@ -1365,26 +1422,22 @@ int launch_slab_pass(lbm_ctx* c, Slab& s, const SlabNb& nbr, int K, int q, int t
   // into the K rows this slab recomputes on a neighbour's behalf
   const int ar = (c->p.ny - 2) - s.row0;
   const int flavour = (int)(c->variant & (lbm::kFastMath | lbm::kNtStore));
-  if (K == 8) {
+  if (slab_is_wave(K)) {
     lbm::WaveArgs a;
     a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
     a.plane = s.plane; a.pitch = s.pitch; a.nx = c->p.nx; a.ny = s.nyl;
     a.blocked = s.blocked; a.omega = c->p.omega;
     a.accel_row = lbm::kNoRow; a.accel_out = accel_out ? 1 : 0; a.a1 = a1; a.a2 = a2;
-    a.H = slab_wave_rows(c, s.nyl);
-    a.nwc = cdiv(c->p.nx, 64 - 16); a.nchunks = cdiv(s.nyl, a.H);
-    a.partials = s.partials[q];
+    a.H = slab_wave_rows(c, s.nyl, K);
+    a.y_begin = 0; a.y_end = s.nyl;
+    a.nwc = cdiv(c->p.nx, wave_out_cols(c, K)); a.nchunks = cdiv(s.nyl, a.H);
+    a.partials = s.partials[q]; a.pstride = nb; a.pbase = 0;
     a.prev = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
     if (fold_prev) { a.prev = s.partials[qp]; a.prev_count = nb; a.prev_sum = s.sums + (tt - K); }
     a.src_s = nbr.src_s; a.src_n = nbr.src_n; a.plane_s = nbr.plane_s; a.plane_n = nbr.plane_n;
     a.ny_s = nbr.ny_s; a.ny_n = nbr.ny_n; a.blocked_s = nbr.blk_s; a.blocked_n = nbr.blk_n;
     a.acc_rows[0] = ar; a.acc_rows[1] = ar - c->p.ny; a.acc_rows[2] = ar + c->p.ny;
-    switch (flavour) {
-      case 0: hipLaunchKernelGGL((lbm::lbm_wave<8, 0, true>), dim3(nb), dim3(lbm::kWaveBlock), 0, s.sc, a); break;
-      case 1: hipLaunchKernelGGL((lbm::lbm_wave<8, 1, true>), dim3(nb), dim3(lbm::kWaveBlock), 0, s.sc, a); break;
-      case 2: hipLaunchKernelGGL((lbm::lbm_wave<8, 2, true>), dim3(nb), dim3(lbm::kWaveBlock), 0, s.sc, a); break;
-      default: hipLaunchKernelGGL((lbm::lbm_wave<8, 3, true>), dim3(nb), dim3(lbm::kWaveBlock), 0, s.sc, a); break;
-    }
+    hipLaunchKernelGGL(wave_kernel(K, true, wave_C(c, K), flavour), dim3(nb), dim3(lbm::kWaveBlock), 0, s.sc, a);
   } else {
     using Cfg = lbm::MarchCfg<kMarchK>;
     lbm::MarchArgs a;
@@ -1430,22 +1483,175 @@ int launch_march_slabs(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_pre
   return LBM_OK;
 }
 
-// ---- lbm_wave: K steps per pass, one wave per 64-column strip
-template <int K>
-void launch_wave_k(const lbm_ctx* c, const lbm::WaveArgs& a, int grid, hipStream_t st) {
-  // flavours: IEEE or fast rcp/sqrt x nontemporal stores
-  switch ((int)(c->variant & (lbm::kFastMath | lbm::kNtStore))) {
-    case 0: hipLaunchKernelGGL((lbm::lbm_wave<K, 0>), dim3(grid), dim3(lbm::kWaveBlock), 0, st, a); break;
-    case 1: hipLaunchKernelGGL((lbm::lbm_wave<K, 1>), dim3(grid), dim3(lbm::kWaveBlock), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((lbm::lbm_wave<K, 2>), dim3(grid), dim3(lbm::kWaveBlock), 0, st, a); break;
-    default: hipLaunchKernelGGL((lbm::lbm_wave<K, 3>), dim3(grid), dim3(lbm::kWaveBlock), 0, st, a); break;
-  }
+// ---- lbm_wave across slabs under the RCCL transport (LBM_EXCHANGE_RCCL, one process per GPU or one process with one
+// slab per GPU): GHOST BANDS.  The K rows below and above a slab are kept as the neighbours hold them in two bands per
+// lattice ([9 planes][K rows][pitch], contiguous) and travel once per K steps: after the slab's two EDGE launches (a
+// short chunk of rows at the bottom and one at the top, which produce the K rows each neighbour needs) the rows are
+// packed and sent with ncclSend / ncclRecv on the exchange stream, overlapped with the INTERIOR launch, which touches
+// no ghost row (reference rows: d2q9-bgk.c:971-998 names the planes that cross a row boundary; K steps need all nine
+// planes of K rows).  The kernel is the SLAB flavour that also reads neighbours' rows in place: a band looks to it
+// like a neighbour's lattice of K rows.  Message protocol: tests/test_slab_gloo.py::test_k_row_ghost_zone_of_the_marching_kernels.
+struct BandPlan { int K, he, H, nwc, nb_s, nb_n, nb_i; };   // edge chunk rows, interior chunk rows, blocks of the three launches
+
+bool march_bands_on(const lbm_ctx* c) {
+  const int K = slab_K(c);
+  if (c->exchange != LBM_EXCHANGE_RCCL || !slab_is_wave(K)) return false;
+  const int rows = c->p.ny / c->nranks;                     // the smallest slab: every rank decides alike
+  if (rows < 4 * K || (double)(rows + 1) * c->slabs[0].pitch * 4.0 >= 4.0e9) return false;
+  for (auto& s : c->slabs) if (!s.band_blk_s) return false;
+  return true;
 }
 
-template <int K>
-int wave_blocks_per_cu() {
+// Edge chunks about half the height of the interior's, so that an edge launch plus the exchange it feeds is over before
+// the interior launch is; interior chunks such that all three launches fit the chip's wave slots in whole rounds.
+BandPlan band_plan(const lbm_ctx* c, const Slab& s) {
+  BandPlan b;
+  b.K = slab_K(c);
+  b.nwc = cdiv(c->p.nx, wave_out_cols(c, b.K));
+  const int hu = slab_wave_rows(c, s.nyl, b.K);
+  b.he = std::max(b.K, std::min(hu / 2, s.nyl / 4));
+  b.H = slab_wave_rows(c, s.nyl - 2 * b.he, b.K, 2 * b.nwc);
+  const int per = lbm::kWaveBlock / 64;
+  b.nb_s = cdiv(b.nwc, per); b.nb_n = b.nb_s;
+  b.nb_i = cdiv((long)b.nwc * cdiv(s.nyl - 2 * b.he, b.H), per);
+  return b;
+}
+
+int bands_setup(lbm_ctx* c, int K) {
+  for (auto& s : c->slabs) {
+    if (s.band_K == K) continue;
+    HIPC(hipSetDevice(s.dev));
+    const size_t bytes = sizeof(float) * 9 * (size_t)K * s.pitch;
+    for (int i = 0; i < 2; ++i) {
+      if (s.band_s[i]) HIPC(hipFree(s.band_s[i]));
+      if (s.band_n[i]) HIPC(hipFree(s.band_n[i]));
+      s.band_s[i] = s.band_n[i] = nullptr;
+      HIPC(hipMalloc((void**)&s.band_s[i], bytes));
+      HIPC(hipMalloc((void**)&s.band_n[i], bytes));
+    }
+    if (s.band_send_s) HIPC(hipFree(s.band_send_s));
+    if (s.band_send_n) HIPC(hipFree(s.band_send_n));
+    s.band_send_s = s.band_send_n = nullptr;
+    HIPC(hipMalloc((void**)&s.band_send_s, bytes));
+    HIPC(hipMalloc((void**)&s.band_send_n, bytes));
+    s.band_K = K;
+  }
+  return LBM_OK;
+}
+
+// The K edge rows of lattice `par` of every local slab to the neighbours' bands of the same parity: on the exchange
+// streams, behind event ev_bnd[q] ("the launches that wrote those rows are over"); ev_recv[q] says the bands have arrived.
+int exchange_bands(lbm_ctx* c, int q, int par, int K) {
+  const int ns = (int)c->slabs.size();
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    HIPC(hipStreamWaitEvent(s.sx, s.ev_bnd[q], 0));
+    hipLaunchKernelGGL(lbm::lbm_pack_band_rows, dim3(cdiv((long)K * s.pitch, 256)), dim3(256), 0, s.sx,
+                       s.lat[par], s.plane, s.pitch, s.nyl, K, s.band_send_s, s.band_send_n);
+    HIPC(hipGetLastError());
+  }
+  NCCLC(rccl::GroupStart());
+  for (int i = 0; i < ns; ++i) {
+    Slab& s = c->slabs[i];
+    const size_t n = 9 * (size_t)K * s.pitch;
+    const int me = c->rank_mode ? c->rank : i;
+    const int south = (me + c->nranks - 1) % c->nranks, north = (me + 1) % c->nranks;
+    // order matters when south == north (1 or 2 ranks): sends S then N, receives N then S
+    NCCLC(rccl::Send(s.band_send_s, n, rccl::kFloat32, south, s.comm, s.sx));
+    NCCLC(rccl::Send(s.band_send_n, n, rccl::kFloat32, north, s.comm, s.sx));
+    NCCLC(rccl::Recv(s.band_n[par], n, rccl::kFloat32, north, s.comm, s.sx));
+    NCCLC(rccl::Recv(s.band_s[par], n, rccl::kFloat32, south, s.comm, s.sx));
+  }
+  NCCLC(rccl::GroupEnd());
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    HIPC(hipEventRecord(s.ev_recv[q], s.sx));
+  }
+  return LBM_OK;
+}
+
+// One launch of lbm_wave<K, ., SLAB> over rows [y0, y1) of a slab whose ghost rows live in bands.
+int launch_band_rows(lbm_ctx* c, Slab& s, const BandPlan& b, int y0, int y1, int H, int nblocks, int pbase, int q, int tt,
+                     bool accel_out, bool fold_prev, hipStream_t st) {
+  const int K = b.K, qp = q ^ 1, ntot = b.nb_s + b.nb_n + b.nb_i;
+  lbm::WaveArgs a;
+  a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
+  a.plane = s.plane; a.pitch = s.pitch; a.nx = c->p.nx; a.ny = s.nyl;
+  a.blocked = s.blocked; a.omega = c->p.omega;
+  a.accel_row = lbm::kNoRow; a.accel_out = accel_out ? 1 : 0;
+  a.a1 = c->p.density * c->p.accel / 9.f; a.a2 = c->p.density * c->p.accel / 36.f;
+  a.H = H; a.y_begin = y0; a.y_end = y1;
+  a.nwc = b.nwc; a.nchunks = cdiv(y1 - y0, H);
+  a.partials = s.partials[q]; a.pstride = ntot; a.pbase = pbase;
+  a.prev = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
+  if (fold_prev) { a.prev = s.partials[qp]; a.prev_count = ntot; a.prev_sum = s.sums + (tt - K); }
+  const long bplane = (long)K * s.pitch;
+  a.src_s = s.band_s[c->cur]; a.src_n = s.band_n[c->cur]; a.plane_s = bplane; a.plane_n = bplane;
+  a.ny_s = K; a.ny_n = K;
+  a.blocked_s = s.band_blk_s + (size_t)(kBandRows - K) * s.pitch; a.blocked_n = s.band_blk_n;
+  const int ar = (c->p.ny - 2) - s.row0;
+  a.acc_rows[0] = ar; a.acc_rows[1] = ar - c->p.ny; a.acc_rows[2] = ar + c->p.ny;
+  hipLaunchKernelGGL(wave_kernel(K, true, wave_C(c, K), (int)(c->variant & (lbm::kFastMath | lbm::kNtStore))),
+                     dim3(nblocks), dim3(lbm::kWaveBlock), 0, st, a);
+  HIPC(hipGetLastError());
+  return LBM_OK;
+}
+
+// One marching group (K steps) of every local slab: edge launches, exchange of the new edge rows, interior launch.
+int launch_band_group(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev) {
+  const int q = li & 1, qp = q ^ 1, K = slab_K(c);
+  int rc;
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    const BandPlan b = band_plan(c, s);
+    hipStream_t es = edge_stream(c, s);
+    HIPC(hipStreamWaitEvent(es, s.ev_recv[qp], 0));                       // the bands of the source lattice have arrived
+    if (es != s.sc) HIPC(hipStreamWaitEvent(es, s.ev_int[qp], 0));        // the previous interior launch is over
+    if ((rc = launch_band_rows(c, s, b, 0, b.he, b.he, b.nb_s, 0, q, tt, accel_out, fold_prev, es))) return rc;
+    if ((rc = launch_band_rows(c, s, b, s.nyl - b.he, s.nyl, b.he, b.nb_n, b.nb_s, q, tt, accel_out, false, es))) return rc;
+    HIPC(hipEventRecord(s.ev_bnd[q], es));
+  }
+  if ((rc = exchange_bands(c, q, c->cur ^ 1, K))) return rc;
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    const BandPlan b = band_plan(c, s);
+    const bool split = split_edge_stream(c, s);
+    if (split) HIPC(hipStreamWaitEvent(s.sc, s.ev_bnd[qp], 0));           // the previous edge launches are over
+    if ((rc = launch_band_rows(c, s, b, b.he, s.nyl - b.he, b.H, b.nb_i, b.nb_s + b.nb_n, q, tt, accel_out, false, s.sc))) return rc;
+    if (split) HIPC(hipEventRecord(s.ev_int[q], s.sc));
+  }
+  c->cur ^= 1;
+  return LBM_OK;
+}
+
+// ---- lbm_wave: K steps per pass, one wave per strip of 64 (or 128) columns
+// The instantiations: a lattice alone (K = 4, 6, 8; one column per lane, or two at K = 6, 8) and a slab with neighbours
+// (K = 6, 8); flavour = IEEE or fast rcp / sqrt (bit 0) x nontemporal stores (bit 1).
+template <int K, bool SLAB, int C>
+wave_fn wave_kernel_f(int flavour) {
+  switch (flavour & 3) {
+    case 0: return lbm::lbm_wave<K, 0, SLAB, C>;
+    case 1: return lbm::lbm_wave<K, 1, SLAB, C>;
+    case 2: return lbm::lbm_wave<K, 2, SLAB, C>;
+    default: return lbm::lbm_wave<K, 3, SLAB, C>;
+  }
+}
+wave_fn wave_kernel(int K, bool slab, int C, int flavour) {
+  if (slab) {
+    if (K == 8) return C == 2 ? wave_kernel_f<8, true, 2>(flavour) : wave_kernel_f<8, true, 1>(flavour);
+    return C == 2 ? wave_kernel_f<6, true, 2>(flavour) : wave_kernel_f<6, true, 1>(flavour);
+  }
+  if (K == 8) return C == 2 ? wave_kernel_f<8, false, 2>(flavour) : wave_kernel_f<8, false, 1>(flavour);
+  if (K == 6) return C == 2 ? wave_kernel_f<6, false, 2>(flavour) : wave_kernel_f<6, false, 1>(flavour);
+  return wave_kernel_f<4, false, 1>(flavour);
+}
+
+int wave_blocks_per_cu(int K, int C) {
+  static int cache[16][3] = {};                 // (the answer does not change; lbm_set_option asks often)
+  if (K < 16 && C < 3 && cache[K][C] > 0) return cache[K][C];
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, lbm::lbm_wave<K, 1>, lbm::kWaveBlock, 0) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(wave_kernel(K, false, C, 1)), lbm::kWaveBlock, 0) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+  if (K < 16 && C < 3) cache[K][C] = n;
   return n;
 }
 
@@ -1455,7 +1661,7 @@ int wave_blocks_per_cu() {
 // K = 6: 229 237 244 246 237; K = 8: 198 212 224 227 228; one resident round of 511-row chunks: 153 at K = 4).
 void wave_plan(lbm_ctx* c) {
   const int K = c->time_block;
-  int bpc = (K == 8) ? wave_blocks_per_cu<8>() : (K == 6) ? wave_blocks_per_cu<6>() : wave_blocks_per_cu<4>();
+  int bpc = wave_blocks_per_cu(K, wave_C(c, K));
   if (bpc < 1) bpc = 4;
   c->wave_capacity = std::max(c->ncu, 1) * bpc * (lbm::kWaveBlock / 64);
   if (c->wave_rows > 0) return;
@@ -1476,23 +1682,20 @@ int launch_wave(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev) {
   a.accel_row = c->p.ny - 2; a.accel_out = accel_out ? 1 : 0;
   a.a1 = c->p.density * c->p.accel / 9.f; a.a2 = c->p.density * c->p.accel / 36.f;
   a.H = c->wave_rows;
-  a.nwc = cdiv(c->p.nx, 64 - 2 * K); a.nchunks = cdiv(c->p.ny, a.H);
+  a.y_begin = 0; a.y_end = c->p.ny;
+  a.nwc = cdiv(c->p.nx, wave_out_cols(c, K)); a.nchunks = cdiv(c->p.ny, a.H);
   const int nb = cdiv((long)a.nwc * a.nchunks, lbm::kWaveBlock / 64);
   if ((long)K * nb > s.partial_cap) return fail(LBM_EINVAL, "lbm_wave: %d blocks exceed the partial-sum buffer (raise wave_rows)", nb);
-  a.partials = s.partials[q];
+  a.partials = s.partials[q]; a.pstride = nb; a.pbase = 0;
   a.prev = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
   if (fold_prev) { a.prev = s.partials[qp]; a.prev_count = nb; a.prev_sum = s.sums + (tt - K); }
-  switch (K) {
-    case 8: launch_wave_k<8>(c, a, nb, s.sc); break;
-    case 6: launch_wave_k<6>(c, a, nb, s.sc); break;
-    default: launch_wave_k<4>(c, a, nb, s.sc); break;
-  }
+  hipLaunchKernelGGL(wave_kernel(K, false, wave_C(c, K), (int)(c->variant & (lbm::kFastMath | lbm::kNtStore))), dim3(nb), dim3(lbm::kWaveBlock), 0, s.sc, a);
   HIPC(hipGetLastError());
   c->cur ^= 1;
   return LBM_OK;
 }
 inline int wave_blocks(const lbm_ctx* c) {
-  return cdiv((long)cdiv(c->p.nx, 64 - 2 * c->time_block) * cdiv(c->p.ny, c->wave_rows), lbm::kWaveBlock / 64);
+  return cdiv((long)cdiv(c->p.nx, wave_out_cols(c, c->time_block)) * cdiv(c->p.ny, c->wave_rows), lbm::kWaveBlock / 64);
 }
 
 // The blocks of one marching launch must fit the per-block partial sums (K floats per block).  Asked BEFORE anything
@@ -1818,7 +2021,7 @@ bool p2p_march_pays(const lbm_ctx* c) {                      // same estimate as
 bool slab_wave_pays(const lbm_ctx* c, int rows) {
   if (c->p.nx < 64 || rows < 32 || c->march_kernel == 0) return false;
   const int h = slab_wave_rows(c, rows);
-  return (double)cdiv(c->p.nx, 64 - 16) * cdiv(rows, h) >= 0.85 * wave_slots(c);
+  return (double)cdiv(c->p.nx, wave_out_cols(c, 8)) * cdiv(rows, h) >= 0.85 * wave_slots(c);
 }
 
 // The step loop with peer-to-peer halos: one stream per slab, no events, no host-side exchange.
@@ -2025,7 +2228,16 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
     if ((rc = ensure_sums(s, nsteps))) return rc;
 
   const bool slabs_march = ex && march_slabs_on(c) && nsteps >= slab_K(c);
+  const bool bands = ex && !slabs_march && march_bands_on(c) && nsteps >= slab_K(c);   // RCCL transport: ghost bands
   if ((slabs_march || nsteps >= c->time_block) && (rc = check_march_partials(c, slabs_march))) return rc;   // (before anything is queued)
+  if (bands) {
+    if ((rc = bands_setup(c, slab_K(c)))) return rc;
+    for (auto& s : c->slabs) {
+      const BandPlan b = band_plan(c, s);
+      if ((long)b.K * (b.nb_s + b.nb_n + b.nb_i) > s.partial_cap)
+        return fail(LBM_EINVAL, "marching kernel: %d blocks exceed the partial-sum buffer (raise wave_rows)", b.nb_s + b.nb_n + b.nb_i);
+    }
+  }
 
   // ---- prologue: accelerate phase of the first step
   for (auto& s : c->slabs) {
@@ -2054,7 +2266,16 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
     }
     return pairs ? exchange_halos(c, par, 0, lbm::kHaloSlots) : exchange_halos(c, par, 3, 3);
   };
-  if (ex && !slabs_march && (rc = prime_halos(1))) return rc;
+  if (ex && !slabs_march && !bands && (rc = prime_halos(1))) return rc;
+  if (bands) {
+    // the ghost bands of the starting lattice, as "group -1" (parity 1 of the events)
+    for (auto& s : c->slabs) {
+      HIPC(hipSetDevice(s.dev));
+      HIPC(hipEventRecord(s.ev_bnd[1], s.sc));
+      if (split_edge_stream(c, s)) HIPC(hipEventRecord(s.ev_int[1], s.sc));
+    }
+    if ((rc = exchange_bands(c, 1, c->cur, slab_K(c)))) return rc;
+  }
 
   const auto wall0 = std::chrono::steady_clock::now();
   for (auto& s : c->slabs) {
@@ -2066,6 +2287,21 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
   // Launch index li numbers the launch groups (a pair of steps or a single step); its parity
   // selects the halo / partial-sum buffers.
   int li = 0, tt = 0;
+  if (bands) {                                         // groups of K steps, ghost bands by RCCL once per group
+    const int K = slab_K(c), ngroups = nsteps / K;
+    for (int g = 0; g < ngroups; ++g, ++li, tt += K)
+      if ((rc = launch_band_group(c, li, tt, tt + K < nsteps, g > 0))) return rc;
+    const int ql = (li - 1) & 1;
+    for (auto& s : c->slabs) {
+      HIPC(hipSetDevice(s.dev));
+      if (split_edge_stream(c, s)) HIPC(hipStreamWaitEvent(s.sc, s.ev_bnd[ql], 0));   // join the edge stream
+      const BandPlan b = band_plan(c, s);
+      const int nb = b.nb_s + b.nb_n + b.nb_i;
+      hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(K), dim3(lbm::kBlock), 0, s.sc, s.partials[ql], nb, s.sums + (tt - K), nb);
+      HIPC(hipGetLastError());
+    }
+    if (tt < nsteps && (rc = prime_halos((li & 1) ^ 1))) return rc;   // the remaining steps trade halos
+  } else
   if (slabs_march) {                                   // groups of K steps, row-marching, every slab of this process
     const int K = slab_K(c), ngroups = nsteps / K;
     for (int g = 0; g < ngroups; ++g, ++li, tt += K)
@@ -2287,6 +2523,12 @@ extern "C" int lbm_set_option(lbm_ctx* c, const char* key, long value) {
       if (check_march_partials(c, c->exchange != 0 && (p2p_march_on(c) || (c->exchange != LBM_EXCHANGE_P2P && march_slabs_on(c))))) { c->wave_rows = was; return LBM_EINVAL; } }
     return LBM_OK;
   }
+  if (!strcmp(key, "wave_cols")) {
+    if (value != 1 && value != 2) return fail(LBM_EINVAL, "wave_cols must be 1 or 2 (columns per lane of lbm_wave)");
+    if (value != c->wave_cols) { c->wave_rows = 0; c->wave_capacity = 0; }
+    c->wave_cols = (int)value;
+    return LBM_OK;
+  }
   if (!strcmp(key, "time_block")) {
     if (value != 1 && value != 2 && value != 4 && value != 6 && value != 8) return fail(LBM_EINVAL, "time_block must be 1, 2, 4, 6 or 8");
     if (value != c->time_block) { c->wave_rows = 0; c->wave_capacity = 0; if (c->march_slabs == 0) c->march_slabs = -1; }   // (what the slabs can march depends on K)
@@ -2326,12 +2568,15 @@ extern "C" int lbm_get_info(const lbm_ctx* c, const char* key, double* value) {
   if (!strcmp(key, "time_block")) { *value = c->time_block; return LBM_OK; }
   if (!strcmp(key, "t2_threads")) { *value = c->t2_threads; return LBM_OK; }
   if (!strcmp(key, "time_block_active")) {
-    *value = (march_eligible(c) || p2p_march_on(c) || (c->exchange != 0 && c->exchange != LBM_EXCHANGE_P2P && march_slabs_on(const_cast<lbm_ctx*>(c))))
+    *value = (march_eligible(c) || p2p_march_on(c) || march_bands_on(c) || (c->exchange != 0 && c->exchange != LBM_EXCHANGE_P2P && march_slabs_on(const_cast<lbm_ctx*>(c))))
                  ? c->time_block : t2_eligible(c) ? 2 : 1;
     return LBM_OK;
   }
-  if (!strcmp(key, "march_kernel")) { *value = ((march_eligible(c) && use_wave_kernel(c)) || (c->exchange != 0 && slab_K(c) == 8)) ? 1 : 0; return LBM_OK; }
+  if (!strcmp(key, "march_kernel")) { *value = ((march_eligible(c) && use_wave_kernel(c)) || (c->exchange != 0 && slab_is_wave(slab_K(c)))) ? 1 : 0; return LBM_OK; }
   if (!strcmp(key, "wave_rows")) { *value = c->wave_rows; return LBM_OK; }
+  if (!strcmp(key, "wave_cols")) { *value = c->wave_cols; return LBM_OK; }
+  if (!strcmp(key, "wave_cols_active")) { *value = wave_C(c, c->time_block); return LBM_OK; }   // what lbm_wave<time_block> would run with
+  if (!strcmp(key, "wave_out_cols")) { *value = wave_out_cols(c, c->time_block); return LBM_OK; }
   if (!strcmp(key, "wave_capacity")) { *value = c->wave_capacity; return LBM_OK; }
   if (!strcmp(key, "march_rows")) { *value = c->march_rows > 0 ? c->march_rows : march_pick_rows(c); return LBM_OK; }
   if (!strcmp(key, "fluid_cells")) { *value = (double)c->tot_fluid; return LBM_OK; }

@@ -874,6 +874,20 @@ __global__ void lbm_pack_halos9(const float* lat, long plane, int pitch, int nx,
   }
 }
 
+// Ghost bands of the marching kernels under the RCCL transport: the K bottom rows of all nine planes packed for the
+// southern neighbour (they become its northern band), the K top rows for the northern one.  out_* = [9][K][pitch].
+__global__ void lbm_pack_band_rows(const float* lat, long plane, int pitch, int nyl, int K, float* out_s, float* out_n) {
+  const long n = (long)K * pitch;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long top = (long)(nyl - K) * pitch;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    out_s[k * n + i] = lat[k * plane + i];
+    out_n[k * n + i] = lat[k * plane + top + i];
+  }
+}
+
 // Folds block partials into slab sums (after the last step of a run): block b folds the `count`
 // floats at partials + b*stride into out[b] -- both steps of a final pair in one launch.
 __global__ __launch_bounds__(kBlock) void lbm_fold_partials(const float* partials, int count, double* out, int stride) {

@@ -36,8 +36,11 @@ struct WaveArgs {
   int accel_out;               // apply the accelerate phase of step t+K+1 to the outputs
   float a1, a2;
   int H;                       // rows per chunk
-  int nwc, nchunks;            // wave columns (of 64 - 2K output columns) x chunks = waves with work
-  float* partials;             // [K][gridDim.x]: per block, speed sums of steps t+1 .. t+K
+  int y_begin, y_end;          // rows this launch covers, in chunks of H from y_begin ([0, ny): the whole lattice / slab)
+  int nwc, nchunks;            // wave columns (of 64 C - 2K output columns) x chunks = waves with work
+  float* partials;             // [K][pstride]: per block, speed sums of steps t+1 .. t+K; this launch's blocks start at pbase
+  int pstride, pbase;          // (one launch per group: pstride = gridDim.x, pbase = 0; a group of several launches -- the
+                               // edge chunks before the ghost-row exchange, the interior chunks beside it -- shares one array)
   const float* prev;           // the previous launch's partials, folded by block 0 (or nullptr)
   int prev_count;              // its block count
   double* prev_sum;            // K doubles
@@ -63,15 +66,24 @@ __device__ __forceinline__ float from_east(float v) {   // wave_shl:1
 }
 
 // waves per SIMD the register allocation must leave room for: the loop is a chain of K dependent cell
-// updates per iteration, so it is other waves, not instruction-level parallelism, that keep a SIMD busy
-constexpr int wave_min_occupancy(int K) { return K <= 6 ? 4 : 3; }
+// updates per iteration, so it is other waves, not instruction-level parallelism, that keep a SIMD busy.
+// Two columns per lane (C = 2) double the registers AND the independent work per wave: two waves per SIMD then
+// issue what four did (a SIMD needs two waves to issue every cycle pair, MI355X_MICROARCH.md, wave scheduling).
+constexpr int wave_min_occupancy(int K, int C = 1) { return C == 2 ? 2 : (K <= 6 ? 4 : 3); }
 
-template <int K, int MODE, bool SLAB = false>
-__global__ __launch_bounds__(kWaveBlock) __attribute__((amdgpu_waves_per_eu(wave_min_occupancy(K))))
+// C = columns per lane.  C = 1: the wave covers 64 columns and delivers 64 - 2K.  C = 2: a lane owns columns
+// 2 lane, 2 lane + 1 of a 128-column strip (one aligned 8-byte access per plane and row), the wave delivers 128 - 2K
+// -- 112 of 128 at K = 8 instead of 48 of 64 -- and half of the east / west neighbours are the lane's own other
+// column: six DPP shifts per PAIR of cells instead of twelve.  Needs K and nx even (a lane's pair never straddles the
+// periodic wrap, and is delivered or dropped as a whole).
+template <int K, int MODE, bool SLAB = false, int C = 1>
+__global__ __launch_bounds__(kWaveBlock) __attribute__((amdgpu_waves_per_eu(wave_min_occupancy(K, C))))
 void lbm_wave(const WaveArgs a) {
   constexpr bool FAST = (MODE & kFastMath) != 0, NTS = (MODE & kNtStore) != 0, NTL = (MODE & kNtLoad) != 0;
-  constexpr int VW = 64 - 2 * K;
+  constexpr int VW = 64 * C - 2 * K;
   static_assert(K >= 1 && K <= 12, "a wave must keep some columns");
+  static_assert(C == 1 || (C == 2 && K % 2 == 0), "one or two columns per lane; pairs need an even K");
+  using fC = std::conditional_t<C == 1, float, f2a>;     // a lane's columns of one plane and row: one aligned access
   __shared__ double red_d[kWaveBlock / 64];
   __shared__ float red_f[kWaveBlock / 64][K];
 
@@ -104,21 +116,22 @@ void lbm_wave(const WaveArgs a) {
 
   if (g < a.nwc * a.nchunks) {
     const int chunk = g / a.nwc, wc = g - chunk * a.nwc;
-    const int X0 = wc * VW, Y0 = chunk * a.H;
-    const int wx = min(VW, a.nx - X0), hy = min(a.H, a.ny - Y0);
+    // rows [y_begin, y_end) of the lattice / slab in chunks of H rows (y_begin = 0, y_end = ny: all of it)
+    const int X0 = wc * VW, Y0 = a.y_begin + chunk * a.H;
+    const int wx = min(VW, a.nx - X0), hy = min(a.H, a.y_end - Y0);
     const int S0 = Y0 - K;                      // first source row
     const int niter = hy + 2 * K;
-    int gx = X0 - K + lane;                     // this lane's column (periodic)
+    int gx = X0 - K + C * lane;                 // this lane's (first) column (periodic)
     gx += (gx < 0) ? a.nx : 0; gx -= (gx >= a.nx) ? a.nx : 0;
-    const bool out_ok = (lane >= K) && (lane < K + wx);
+    const bool out_ok = (C * lane >= K) && (C * lane < K + wx);
     // row walk of the loads: byte offset of (row, column) inside a plane / inside the obstacle map
     int gy = S0 % a.ny; gy += (gy < 0) ? a.ny : 0;
     unsigned ld_off = ((unsigned)gy * (unsigned)a.pitch + (unsigned)gx) * 4u;
     const unsigned ld_step = (unsigned)a.pitch * 4u, ld_back = (unsigned)(a.ny - 1) * (unsigned)a.pitch * 4u;
     // ... of the stores (level K's first row is Y0; its columns never wrap)
-    unsigned st_off = ((unsigned)Y0 * (unsigned)a.pitch + (unsigned)(X0 - K + lane)) * 4u;
+    unsigned st_off = ((unsigned)Y0 * (unsigned)a.pitch + (unsigned)(X0 - K + C * lane)) * 4u;
     // iterations (minus the level) in which a level's row is the accelerate row: the chunk plus its fill
-    // rows may pass it twice
+    // rows may pass it twice (never three times: the host keeps ny >= 2K)
     int jacc = (a.accel_row - S0) % a.ny; jacc += (jacc < 0) ? a.ny : 0;
     int jacc2 = jacc + a.ny, jacc3 = -1;
     if constexpr (SLAB) {                       // nothing wraps in y: the three images of the accelerate row, as they are
@@ -126,83 +139,137 @@ void lbm_wave(const WaveArgs a) {
     }
     int srow = S0;                              // SLAB: the source row about to be loaded, in this slab's numbering
 
-    auto load_row = [&](float (&f)[9], int& blk) {
+    // The source lattice is loaded plane by plane WHERE LEVEL 1 FIRST NEEDS IT, not row by row: for iteration j
+    // planes 4,7,8 of row S0+j (pulled from the row above), planes 0,1,3 of row S0+j-1 (the row itself) and planes 2,5,6 of
+    // row S0+j-2 (the row below) -- every plane of every row still exactly once, and level 1 needs no history registers
+    // (nine fewer per column).  In the first two iterations the two older rows lie outside the chunk's rows: the addresses
+    // are valid (periodic wrap; SLAB: clamped) and nothing uses the values (level 1 starts in iteration 2).
+    auto load_row = [&](float (&f)[C][9], unsigned& blk) {
+      const float *baseA = a.src, *baseB = a.src, *baseC = a.src;
+      long plA = a.plane, plB = a.plane, plC = a.plane;
+      const uint8_t* bl = a.blocked;
+      unsigned offA, offB, offC;
       if constexpr (SLAB) {
-        // rows below 0 live at the top of the southern neighbour's lattice, rows from ny up at the bottom of the northern one's
-        const float* base = a.src; long pl = a.plane; const uint8_t* bl = a.blocked; int r = srow;
-        if (srow < 0) { base = a.src_s; pl = a.plane_s; bl = a.blocked_s; r = srow + a.ny_s; }
-        else if (srow >= a.ny) { base = a.src_n; pl = a.plane_n; bl = a.blocked_n; r = srow - a.ny; }
-        const unsigned off = ((unsigned)r * (unsigned)a.pitch + (unsigned)gx) * 4u;
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-          f[k] = ldg<NTL>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + k * pl) + off));
-        blk = bl[off >> 2];
+        // rows below 0 live at the top of the southern neighbour's lattice (or of the ghost band that mirrors it), rows
+        // from ny up at the bottom of the northern one's
+        auto where = [&](int r, const float*& base, long& pl, const uint8_t** blp) -> unsigned {
+          if (r < 0) { base = a.src_s; pl = a.plane_s; if (blp) *blp = a.blocked_s; r = max(r + a.ny_s, 0); }
+          else if (r >= a.ny) { base = a.src_n; pl = a.plane_n; if (blp) *blp = a.blocked_n; r = r - a.ny; }
+          return ((unsigned)r * (unsigned)a.pitch + (unsigned)gx) * 4u;
+        };
+        offA = where(srow, baseA, plA, &bl);
+        offB = where(srow - 1, baseB, plB, nullptr);
+        offC = where(srow - 2, baseC, plC, nullptr);
         ++srow;
       } else {
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-          f[k] = ldg<NTL>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.src + k * a.plane) + ld_off));
-        blk = a.blocked[ld_off >> 2];
+        offA = ld_off;
+        offB = (gy == 0) ? ld_off + ld_back : ld_off - ld_step;
+        offC = (gy == 0) ? ld_off + ld_back - ld_step : (gy == 1) ? ld_off - ld_step + ld_back : ld_off - 2u * ld_step;
+      }
+      auto ld = [&](int k, const float* base, long pl, unsigned off) {
+        const fC v = ldg<NTL>(reinterpret_cast<const fC*>(reinterpret_cast<const char*>(base + k * pl) + off));
+        if constexpr (C == 1) { f[0][k] = v; } else { f[0][k] = v.x; f[1][k] = v.y; }
+      };
+      ld(4, baseA, plA, offA); ld(7, baseA, plA, offA); ld(8, baseA, plA, offA);
+      ld(0, baseB, plB, offB); ld(1, baseB, plB, offB); ld(3, baseB, plB, offB);
+      ld(2, baseC, plC, offC); ld(5, baseC, plC, offC); ld(6, baseC, plC, offC);
+      if constexpr (C == 1) blk = bl[offA >> 2];
+      else blk = *reinterpret_cast<const uint16_t*>(bl + (offA >> 2));     // byte c = column c
+      if constexpr (!SLAB) {
         ++gy;
         if (gy == a.ny) { gy = 0; ld_off -= ld_back; } else { ld_off += ld_step; }
       }
     };
 
     {
-    // interface l (between level l and level l+1): planes 0,1,3 of the producer's previous row, planes 2,5,6
-    // of its previous two rows
-    float Bp[K][3], C1[K][3], C2[K][3];
+    // interface l (between level l and level l+1, l >= 1; level 1 pulls from the loads themselves): planes 0,1,3 of
+    // the producer's previous row, planes 2,5,6 of its previous two rows  (index 0 of the arrays is never used)
+    float Bp[K][C][3], C1[K][C][3], C2[K][C][3];
 #pragma unroll
     for (int l = 0; l < K; ++l)
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { Bp[l][i] = 1.f; C1[l][i] = 1.f; C2[l][i] = 1.f; }
-    unsigned mreg = 0u;                          // bit l = obstacle flag of the row level l works on
-    float nxt[9]; int nblk;
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { Bp[l][c][i] = 1.f; C1[l][c][i] = 1.f; C2[l][c][i] = 1.f; }
+    unsigned mreg[C];                            // bit l = obstacle flag of the row level l works on, per column
+#pragma unroll
+    for (int c = 0; c < C; ++c) mreg[c] = 0u;
+    float nxt[C][9]; unsigned nblk;
     load_row(nxt, nblk);
     // One iteration.  STEADY: past the 2K fill iterations of the chunk every level has its history, the "is this level
     // running yet" tests are gone and with them the register copies their merge points force (a quarter of the loop).
     auto iteration = [&](auto steady_c, int j) {
       constexpr bool STEADY = decltype(steady_c)::value;
-      float cur[9];
+      float cur[C][9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) cur[k] = nxt[k];
-      mreg = (mreg << 1) | (nblk != 0 ? 1u : 0u);
+      for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) cur[c][k] = nxt[c][k];
+        mreg[c] = (mreg[c] << 1) | (((nblk >> (8 * c)) & 0xffu) != 0u ? 1u : 0u);
+      }
       if (j + 1 < niter) load_row(nxt, nblk);    // next iteration's source row, in flight behind this one's arithmetic
 #pragma unroll
       for (int l = 1; l <= K; ++l) {
-        float p[9];
+        float p[C][9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) p[k] = cur[k];
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+          for (int k = 0; k < 9; ++k) p[c][k] = cur[c][k];
         if (STEADY || j >= 2 * l) {
-          // pull (d2q9-bgk.c:2139-2147): row above = cur, same row = Bp, row below = C2 of interface l-1
-          p[0] = Bp[l - 1][0];
-          p[1] = from_west(Bp[l - 1][1]);
-          p[3] = from_east(Bp[l - 1][2]);
-          p[2] = C2[l - 1][0];
-          p[5] = from_west(C2[l - 1][1]);
-          p[6] = from_east(C2[l - 1][2]);
-          p[4] = cur[4];
-          p[7] = from_east(cur[7]);
-          p[8] = from_west(cur[8]);
-          const bool blk = ((mreg >> l) & 1u) != 0u;
-          const float sp = collide_cell<FAST>(p, blk, a.omega);
-          const int jl = j - l;
-          if ((jl == jacc || jl == jacc2 || (SLAB && jl == jacc3)) && (l < K || a.accel_out != 0)) accelerate_cell(p, blk, a.a1, a.a2);
-          sum[l - 1] += (out_ok && jl >= K && jl < K + hy) ? sp : 0.f;
+          // pull (d2q9-bgk.c:2139-2147): row above = cur, same row = Bp, row below = C2 of interface l-1.
+          // The column to the west of column c is the lane's own column c-1, or (c = 0) the last column of the lane
+          // to the west: one whole-wave DPP shift; likewise to the east.
+          const bool acc = ((j - l == jacc) || (j - l == jacc2) || (SLAB && j - l == jacc3)) && (l < K || a.accel_out != 0);
+          const bool own_row = (j - l >= K) && (j - l < K + hy);
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const int cw = (c == 0) ? C - 1 : c - 1, ce = (c == C - 1) ? 0 : c + 1;
+            // (level 1: all nine come straight from this iteration's loads, each plane from the row it is pulled from)
+            const float s0 = (l == 1) ? cur[c][0] : Bp[l - 1][c][0];
+            const float s1 = (l == 1) ? cur[cw][1] : Bp[l - 1][cw][1];
+            const float s3 = (l == 1) ? cur[ce][3] : Bp[l - 1][ce][2];
+            const float s2 = (l == 1) ? cur[c][2] : C2[l - 1][c][0];
+            const float s5 = (l == 1) ? cur[cw][5] : C2[l - 1][cw][1];
+            const float s6 = (l == 1) ? cur[ce][6] : C2[l - 1][ce][2];
+            p[c][0] = s0;
+            p[c][1] = (c == 0) ? from_west(s1) : s1;
+            p[c][3] = (c == C - 1) ? from_east(s3) : s3;
+            p[c][2] = s2;
+            p[c][5] = (c == 0) ? from_west(s5) : s5;
+            p[c][6] = (c == C - 1) ? from_east(s6) : s6;
+            p[c][4] = cur[c][4];
+            p[c][7] = (c == C - 1) ? from_east(cur[ce][7]) : cur[ce][7];
+            p[c][8] = (c == 0) ? from_west(cur[cw][8]) : cur[cw][8];
+          }
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const bool blk = ((mreg[c] >> l) & 1u) != 0u;
+            const float sp = collide_cell<FAST>(p[c], blk, a.omega);
+            if (acc) accelerate_cell(p[c], blk, a.a1, a.a2);
+            sum[l - 1] += (out_ok && own_row) ? sp : 0.f;
+          }
         }
-        if (STEADY || j >= 2 * (l - 1)) {        // the producer's row of this iteration becomes history for the next two
-          C2[l - 1][0] = C1[l - 1][0]; C2[l - 1][1] = C1[l - 1][1]; C2[l - 1][2] = C1[l - 1][2];
-          C1[l - 1][0] = cur[2]; C1[l - 1][1] = cur[5]; C1[l - 1][2] = cur[6];
-          Bp[l - 1][0] = cur[0]; Bp[l - 1][1] = cur[1]; Bp[l - 1][2] = cur[3];
+        if (l >= 2 && (STEADY || j >= 2 * (l - 1))) {   // the producer's row of this iteration becomes history for the next two
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            C2[l - 1][c][0] = C1[l - 1][c][0]; C2[l - 1][c][1] = C1[l - 1][c][1]; C2[l - 1][c][2] = C1[l - 1][c][2];
+            C1[l - 1][c][0] = cur[c][2]; C1[l - 1][c][1] = cur[c][5]; C1[l - 1][c][2] = cur[c][6];
+            Bp[l - 1][c][0] = cur[c][0]; Bp[l - 1][c][1] = cur[c][1]; Bp[l - 1][c][2] = cur[c][3];
+          }
         }
 #pragma unroll
-        for (int k = 0; k < 9; ++k) cur[k] = p[k];
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+          for (int k = 0; k < 9; ++k) cur[c][k] = p[c][k];
       }
       if (STEADY || j >= 2 * K) {                // level K's row S0 + j - K = Y0 + (j - 2K)
         if (out_ok) {
 #pragma unroll
-          for (int k = 0; k < 9; ++k)
-            stg<NTS>(reinterpret_cast<float*>(reinterpret_cast<char*>(a.dst + k * a.plane) + st_off), cur[k]);
+          for (int k = 0; k < 9; ++k) {
+            fC v;
+            if constexpr (C == 1) { v = cur[0][k]; } else { v.x = cur[0][k]; v.y = cur[1][k]; }
+            stg<NTS>(reinterpret_cast<fC*>(reinterpret_cast<char*>(a.dst + k * a.plane) + st_off), v);
+          }
         }
         st_off += ld_step;
       }
@@ -220,7 +287,7 @@ void lbm_wave(const WaveArgs a) {
     if (lane == 0) red_f[w][l] = s;
   }
   __syncthreads();
-  if (tid < K) a.partials[(long)tid * nb + blockIdx.x] = red_f[0][tid] + red_f[1][tid] + red_f[2][tid] + red_f[3][tid];
+  if (tid < K) a.partials[(long)tid * a.pstride + a.pbase + blockIdx.x] = red_f[0][tid] + red_f[1][tid] + red_f[2][tid] + red_f[3][tid];
 }
 
 }  // namespace lbm

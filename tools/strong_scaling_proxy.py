@@ -9,15 +9,18 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dir
 import torch  # noqa: F401,E402  (before the HIP library)
 import advanced_hpc_lbm_amd as L  # noqa: E402
 os.environ["LBM_FORCE_EXCHANGE"] = "1"
+only = int(sys.argv[1]) if len(sys.argv) > 1 else 0        # e.g. 8192: that width only
 for nx, ny, label in ((1024, 1024, "1 GPU"), (1024, 512, "rank of 2"), (1024, 256, "rank of 4"), (1024, 128, "rank of 8"),
                       (8192, 8192, "1 GPU"), (8192, 4096, "rank of 2"), (8192, 2048, "rank of 4"), (8192, 1024, "rank of 8")):
+    if only and nx != only:
+        continue
     p = L.Param(nx, ny, 1000, 10, 0.1, 0.01, 1.85)
     ob = np.zeros((ny, nx), np.int32)
     ob[:, 0] = ob[:, -1] = 1
     ob[:, nx // 3] = 1
     steps = 4000 if nx == 1024 else 208
     whole = (1024 * 1024 if nx == 1024 else 8192 * 8192) / (nx * ny)
-    for mode, name, tb in ((L.EXCHANGE_P2P, "p2p default", 0), (L.EXCHANGE_P2P, "p2p lbm_wave<8>", 8), (L.EXCHANGE_P2P, "p2p lbm_sweep2", 2), (L.EXCHANGE_RCCL, "rccl", 0)):
+    for mode, name, tb in ((L.EXCHANGE_P2P, "p2p default", 0), (L.EXCHANGE_P2P, "p2p lbm_wave<8>", 8), (L.EXCHANGE_P2P, "p2p lbm_sweep2", 2), (L.EXCHANGE_RCCL, "rccl", 0), (L.EXCHANGE_RCCL, "rccl lbm_sweep2", 2)):
         if tb == 8 and ny < 32:
             continue
         with L.Lattice(p, ob, rank=0, nranks=1, device=0, unique_id=L.rccl_unique_id(), exchange=mode) as lat:
