@@ -738,7 +738,7 @@ wave_fn wave_kernel(int K, bool slab, int C, int flavour);   // the lbm_wave ins
 bool march_slabs_setup(lbm_ctx* c);   // marching kernel across slabs, below
 int wave_blocks_per_cu(int K, int C);        // occupancy of lbm_wave<K, ., ., C>, below
 bool p2p_march_pays(const lbm_ctx* c);
-bool slab_wave_pays(const lbm_ctx* c, int rows);
+bool slab_wave_pays(const lbm_ctx* c, int rows, int K = 8);
 int slab_wave_rows(const lbm_ctx* c, int ny_rows, int K = 8, int extra_waves = 0);
 double slab_wave_efficiency(const lbm_ctx* c, int ny_rows, int h, int K = 8, int extra_waves = 0);
 int march_rows_for(const lbm_ctx* c, int ny_rows);
@@ -772,7 +772,17 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
       // peer-to-peer halos (one process or one process per GPU): lbm_march where the smallest slab fills the chip
       // (a function of the lattice and the number of slabs only: every rank decides alike)
       if (c->p.nx % 4 == 0 && c->p.nx >= lbm::MarchCfg<kMarchK>::W && c->p.ny / c->nranks >= 4 * kMarchK && p2p_march_pays(c)) c->time_block = 4;
-      if (c->time_block == 4 && c->march_kernel != 0 && !getenv("LBM_MARCH_KERNEL") && slab_wave_pays(c, c->p.ny / c->nranks)) c->time_block = 8;
+      if (c->time_block == 4 && c->march_kernel != 0 && !getenv("LBM_MARCH_KERNEL")) {
+        // lbm_wave<6> with two columns per lane where its (fewer, fatter) waves fill a round of the chip: measured on the
+        // 8192-wide slabs of N = 2 / 4 / 8 (one GPU, ring of one, us per step): 115.2 / 63.6 / 35.3 against lbm_wave<8>'s
+        // 118.9 / 66.7 / 37.4 (profiles/r03_strong_scaling_proxy.log); else lbm_wave<8>, else lbm_march
+        const int rows = c->p.ny / c->nranks;
+        if (!getenv("LBM_WAVE_COLS") && c->p.nx % 2 == 0 && c->p.nx >= 128) {
+          c->wave_cols = 2;
+          if (slab_wave_pays(c, rows, 6)) c->time_block = 6; else c->wave_cols = 1;
+        }
+        if (c->time_block == 4 && slab_wave_pays(c, rows, 8)) c->time_block = 8;
+      }
     } else
     if (!getenv("LBM_TIME_BLOCK") && c->time_block == 2 && exchanging && c->exchange == LBM_EXCHANGE_RCCL) {
       // RCCL halos (one process per GPU, or one process with a slab per GPU): lbm_wave<8> with ghost bands -- K rows of all
@@ -1431,6 +1441,7 @@ int launch_slab_pass(lbm_ctx* c, Slab& s, const SlabNb& nbr, int K, int q, int t
     a.H = slab_wave_rows(c, s.nyl, K);
     a.y_begin = 0; a.y_end = s.nyl;
     a.nwc = cdiv(c->p.nx, wave_out_cols(c, K)); a.nchunks = cdiv(s.nyl, a.H);
+    a.nchunks_a = a.nchunks; a.yb_begin = a.yb_end = 0;
     a.partials = s.partials[q]; a.pstride = nb; a.pbase = 0;
     a.prev = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
     if (fold_prev) { a.prev = s.partials[qp]; a.prev_count = nb; a.prev_sum = s.sums + (tt - K); }
@@ -1491,7 +1502,7 @@ int launch_march_slabs(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_pre
 // no ghost row (reference rows: d2q9-bgk.c:971-998 names the planes that cross a row boundary; K steps need all nine
 // planes of K rows).  The kernel is the SLAB flavour that also reads neighbours' rows in place: a band looks to it
 // like a neighbour's lattice of K rows.  Message protocol: tests/test_slab_gloo.py::test_k_row_ghost_zone_of_the_marching_kernels.
-struct BandPlan { int K, he, H, nwc, nb_s, nb_n, nb_i; };   // edge chunk rows, interior chunk rows, blocks of the three launches
+struct BandPlan { int K, he, H, nwc, nb_e, nb_i; };   // edge chunk rows, interior chunk rows, blocks of the edge launch (both edge chunks) and of the interior launch
 
 bool march_bands_on(const lbm_ctx* c) {
   const int K = slab_K(c);
@@ -1508,11 +1519,14 @@ BandPlan band_plan(const lbm_ctx* c, const Slab& s) {
   BandPlan b;
   b.K = slab_K(c);
   b.nwc = cdiv(c->p.nx, wave_out_cols(c, b.K));
+  // (an edge chunk is one wave per strip marching alone on its SIMD: ~2.2 us per row at K = 8, against ~3.7 for the rows of the
+  // interior launch's three waves per SIMD; LBM_BAND_EDGE_ROWS overrides)
+  static const int edge_rows_env = getenv("LBM_BAND_EDGE_ROWS") ? atoi(getenv("LBM_BAND_EDGE_ROWS")) : 0;
   const int hu = slab_wave_rows(c, s.nyl, b.K);
-  b.he = std::max(b.K, std::min(hu / 2, s.nyl / 4));
+  b.he = std::max(b.K, std::min(edge_rows_env > 0 ? edge_rows_env : hu / 3, s.nyl / 4));
   b.H = slab_wave_rows(c, s.nyl - 2 * b.he, b.K, 2 * b.nwc);
   const int per = lbm::kWaveBlock / 64;
-  b.nb_s = cdiv(b.nwc, per); b.nb_n = b.nb_s;
+  b.nb_e = cdiv(2 * b.nwc, per);
   b.nb_i = cdiv((long)b.nwc * cdiv(s.nyl - 2 * b.he, b.H), per);
   return b;
 }
@@ -1570,18 +1584,24 @@ int exchange_bands(lbm_ctx* c, int q, int par, int K) {
   return LBM_OK;
 }
 
-// One launch of lbm_wave<K, ., SLAB> over rows [y0, y1) of a slab whose ghost rows live in bands.
-int launch_band_rows(lbm_ctx* c, Slab& s, const BandPlan& b, int y0, int y1, int H, int nblocks, int pbase, int q, int tt,
-                     bool accel_out, bool fold_prev, hipStream_t st) {
-  const int K = b.K, qp = q ^ 1, ntot = b.nb_s + b.nb_n + b.nb_i;
+// One launch of lbm_wave<K, ., SLAB> on a slab whose ghost rows live in bands: the interior rows [he, nyl - he) in chunks of
+// H, or (edge) the two edge chunks [0, he) and [nyl - he, nyl) together.
+int launch_band_rows(lbm_ctx* c, Slab& s, const BandPlan& b, bool edge, int q, int tt, bool accel_out, bool fold_prev, hipStream_t st) {
+  const int K = b.K, qp = q ^ 1, ntot = b.nb_e + b.nb_i;
+  const int nblocks = edge ? b.nb_e : b.nb_i, pbase = edge ? 0 : b.nb_e;
   lbm::WaveArgs a;
   a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
   a.plane = s.plane; a.pitch = s.pitch; a.nx = c->p.nx; a.ny = s.nyl;
   a.blocked = s.blocked; a.omega = c->p.omega;
   a.accel_row = lbm::kNoRow; a.accel_out = accel_out ? 1 : 0;
   a.a1 = c->p.density * c->p.accel / 9.f; a.a2 = c->p.density * c->p.accel / 36.f;
-  a.H = H; a.y_begin = y0; a.y_end = y1;
-  a.nwc = b.nwc; a.nchunks = cdiv(y1 - y0, H);
+  if (edge) {
+    a.H = b.he; a.y_begin = 0; a.y_end = b.he; a.nchunks_a = 1; a.yb_begin = s.nyl - b.he; a.yb_end = s.nyl; a.nchunks = 2;
+  } else {
+    a.H = b.H; a.y_begin = b.he; a.y_end = s.nyl - b.he; a.nchunks = cdiv(a.y_end - a.y_begin, b.H); a.nchunks_a = a.nchunks;
+    a.yb_begin = a.yb_end = 0;
+  }
+  a.nwc = b.nwc;
   a.partials = s.partials[q]; a.pstride = ntot; a.pbase = pbase;
   a.prev = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
   if (fold_prev) { a.prev = s.partials[qp]; a.prev_count = ntot; a.prev_sum = s.sums + (tt - K); }
@@ -1607,8 +1627,7 @@ int launch_band_group(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev
     hipStream_t es = edge_stream(c, s);
     HIPC(hipStreamWaitEvent(es, s.ev_recv[qp], 0));                       // the bands of the source lattice have arrived
     if (es != s.sc) HIPC(hipStreamWaitEvent(es, s.ev_int[qp], 0));        // the previous interior launch is over
-    if ((rc = launch_band_rows(c, s, b, 0, b.he, b.he, b.nb_s, 0, q, tt, accel_out, fold_prev, es))) return rc;
-    if ((rc = launch_band_rows(c, s, b, s.nyl - b.he, s.nyl, b.he, b.nb_n, b.nb_s, q, tt, accel_out, false, es))) return rc;
+    if ((rc = launch_band_rows(c, s, b, true, q, tt, accel_out, fold_prev, es))) return rc;
     HIPC(hipEventRecord(s.ev_bnd[q], es));
   }
   if ((rc = exchange_bands(c, q, c->cur ^ 1, K))) return rc;
@@ -1617,7 +1636,7 @@ int launch_band_group(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev
     const BandPlan b = band_plan(c, s);
     const bool split = split_edge_stream(c, s);
     if (split) HIPC(hipStreamWaitEvent(s.sc, s.ev_bnd[qp], 0));           // the previous edge launches are over
-    if ((rc = launch_band_rows(c, s, b, b.he, s.nyl - b.he, b.H, b.nb_i, b.nb_s + b.nb_n, q, tt, accel_out, false, s.sc))) return rc;
+    if ((rc = launch_band_rows(c, s, b, false, q, tt, accel_out, false, s.sc))) return rc;
     if (split) HIPC(hipEventRecord(s.ev_int[q], s.sc));
   }
   c->cur ^= 1;
@@ -1684,12 +1703,16 @@ int launch_wave(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev) {
   a.H = c->wave_rows;
   a.y_begin = 0; a.y_end = c->p.ny;
   a.nwc = cdiv(c->p.nx, wave_out_cols(c, K)); a.nchunks = cdiv(c->p.ny, a.H);
+  a.nchunks_a = a.nchunks; a.yb_begin = a.yb_end = 0;
   const int nb = cdiv((long)a.nwc * a.nchunks, lbm::kWaveBlock / 64);
   if ((long)K * nb > s.partial_cap) return fail(LBM_EINVAL, "lbm_wave: %d blocks exceed the partial-sum buffer (raise wave_rows)", nb);
   a.partials = s.partials[q]; a.pstride = nb; a.pbase = 0;
   a.prev = nullptr; a.prev_count = 0; a.prev_sum = nullptr;
   if (fold_prev) { a.prev = s.partials[qp]; a.prev_count = nb; a.prev_sum = s.sums + (tt - K); }
-  hipLaunchKernelGGL(wave_kernel(K, false, wave_C(c, K), (int)(c->variant & (lbm::kFastMath | lbm::kNtStore))), dim3(nb), dim3(lbm::kWaveBlock), 0, s.sc, a);
+  // (development: LBM_WAVE_PAD_LDS = bytes of unused dynamic LDS per block, to hold fewer blocks on a CU than the registers
+  // allow -- how the rate depends on the waves per SIMD: profiles/r03_wave_occupancy.log)
+  static const int pad_lds = getenv("LBM_WAVE_PAD_LDS") ? atoi(getenv("LBM_WAVE_PAD_LDS")) : 0;
+  hipLaunchKernelGGL(wave_kernel(K, false, wave_C(c, K), (int)(c->variant & (lbm::kFastMath | lbm::kNtStore))), dim3(nb), dim3(lbm::kWaveBlock), pad_lds, s.sc, a);
   HIPC(hipGetLastError());
   c->cur ^= 1;
   return LBM_OK;
@@ -2018,10 +2041,10 @@ bool p2p_march_pays(const lbm_ctx* c) {                      // same estimate as
 // chip's wave slots.  Measured on one GPU (tools/strong_scaling_proxy.py, us per step, lbm_wave<8> against lbm_march):
 // 8192 x 4096 126 / 135, 8192 x 2048 69.3 / 70.3, 8192 x 1024 38.7 / 39.4 -- a little ahead everywhere, with half as
 // many launches (and flag hand-offs over xGMI) per step; 1024-wide slabs (22 wave columns) are far too narrow: 12.4 / 5.4.
-bool slab_wave_pays(const lbm_ctx* c, int rows) {
+bool slab_wave_pays(const lbm_ctx* c, int rows, int K) {
   if (c->p.nx < 64 || rows < 32 || c->march_kernel == 0) return false;
-  const int h = slab_wave_rows(c, rows);
-  return (double)cdiv(c->p.nx, wave_out_cols(c, 8)) * cdiv(rows, h) >= 0.85 * wave_slots(c);
+  const int h = slab_wave_rows(c, rows, K);
+  return (double)cdiv(c->p.nx, wave_out_cols(c, K)) * cdiv(rows, h) >= 0.85 * wave_slots(c, K);
 }
 
 // The step loop with peer-to-peer halos: one stream per slab, no events, no host-side exchange.
@@ -2234,8 +2257,8 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
     if ((rc = bands_setup(c, slab_K(c)))) return rc;
     for (auto& s : c->slabs) {
       const BandPlan b = band_plan(c, s);
-      if ((long)b.K * (b.nb_s + b.nb_n + b.nb_i) > s.partial_cap)
-        return fail(LBM_EINVAL, "marching kernel: %d blocks exceed the partial-sum buffer (raise wave_rows)", b.nb_s + b.nb_n + b.nb_i);
+      if ((long)b.K * (b.nb_e + b.nb_i) > s.partial_cap)
+        return fail(LBM_EINVAL, "marching kernel: %d blocks exceed the partial-sum buffer (raise wave_rows)", b.nb_e + b.nb_i);
     }
   }
 
@@ -2296,7 +2319,7 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
       HIPC(hipSetDevice(s.dev));
       if (split_edge_stream(c, s)) HIPC(hipStreamWaitEvent(s.sc, s.ev_bnd[ql], 0));   // join the edge stream
       const BandPlan b = band_plan(c, s);
-      const int nb = b.nb_s + b.nb_n + b.nb_i;
+      const int nb = b.nb_e + b.nb_i;
       hipLaunchKernelGGL(lbm::lbm_fold_partials, dim3(K), dim3(lbm::kBlock), 0, s.sc, s.partials[ql], nb, s.sums + (tt - K), nb);
       HIPC(hipGetLastError());
     }

@@ -37,6 +37,8 @@ struct WaveArgs {
   float a1, a2;
   int H;                       // rows per chunk
   int y_begin, y_end;          // rows this launch covers, in chunks of H from y_begin ([0, ny): the whole lattice / slab)
+  int nchunks_a;               // chunks of that range; chunks beyond it (up to nchunks) cover a SECOND range of rows --
+  int yb_begin, yb_end;        // the two edge chunks of a slab, bottom and top, in one launch (nchunks_a = nchunks: no second range)
   int nwc, nchunks;            // wave columns (of 64 C - 2K output columns) x chunks = waves with work
   float* partials;             // [K][pstride]: per block, speed sums of steps t+1 .. t+K; this launch's blocks start at pbase
   int pstride, pbase;          // (one launch per group: pstride = gridDim.x, pbase = 0; a group of several launches -- the
@@ -117,8 +119,9 @@ void lbm_wave(const WaveArgs a) {
   if (g < a.nwc * a.nchunks) {
     const int chunk = g / a.nwc, wc = g - chunk * a.nwc;
     // rows [y_begin, y_end) of the lattice / slab in chunks of H rows (y_begin = 0, y_end = ny: all of it)
-    const int X0 = wc * VW, Y0 = a.y_begin + chunk * a.H;
-    const int wx = min(VW, a.nx - X0), hy = min(a.H, a.y_end - Y0);
+    const bool second = chunk >= a.nchunks_a;
+    const int X0 = wc * VW, Y0 = second ? a.yb_begin + (chunk - a.nchunks_a) * a.H : a.y_begin + chunk * a.H;
+    const int wx = min(VW, a.nx - X0), hy = min(a.H, (second ? a.yb_end : a.y_end) - Y0);
     const int S0 = Y0 - K;                      // first source row
     const int niter = hy + 2 * K;
     int gx = X0 - K + C * lane;                 // this lane's (first) column (periodic)

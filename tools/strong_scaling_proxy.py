@@ -10,6 +10,7 @@ import torch  # noqa: F401,E402  (before the HIP library)
 import advanced_hpc_lbm_amd as L  # noqa: E402
 os.environ["LBM_FORCE_EXCHANGE"] = "1"
 only = int(sys.argv[1]) if len(sys.argv) > 1 else 0        # e.g. 8192: that width only
+modes = sys.argv[2].split(",") if len(sys.argv) > 2 else None   # e.g. "p2p default,rccl": those lines only
 for nx, ny, label in ((1024, 1024, "1 GPU"), (1024, 512, "rank of 2"), (1024, 256, "rank of 4"), (1024, 128, "rank of 8"),
                       (8192, 8192, "1 GPU"), (8192, 4096, "rank of 2"), (8192, 2048, "rank of 4"), (8192, 1024, "rank of 8")):
     if only and nx != only:
@@ -21,7 +22,7 @@ for nx, ny, label in ((1024, 1024, "1 GPU"), (1024, 512, "rank of 2"), (1024, 25
     steps = 4000 if nx == 1024 else 208
     whole = (1024 * 1024 if nx == 1024 else 8192 * 8192) / (nx * ny)
     for mode, name, tb in ((L.EXCHANGE_P2P, "p2p default", 0), (L.EXCHANGE_P2P, "p2p lbm_wave<8>", 8), (L.EXCHANGE_P2P, "p2p lbm_sweep2", 2), (L.EXCHANGE_RCCL, "rccl", 0), (L.EXCHANGE_RCCL, "rccl lbm_sweep2", 2)):
-        if tb == 8 and ny < 32:
+        if (tb == 8 and ny < 32) or (modes and name not in modes):
             continue
         with L.Lattice(p, ob, rank=0, nranks=1, device=0, unique_id=L.rccl_unique_id(), exchange=mode) as lat:
             if tb:
