@@ -29,7 +29,10 @@ $(LIB): $(PKG)/csrc/lbm_api.hip $(PKG)/csrc/lbm_kernels.hip.h $(PKG)/csrc/lbm_ex
 $(EXE): $(PKG)/host/d2q9-bgk.c $(LIB) include/lbm_mi355x.h
 	$(CC) $(CFLAGS) -Iinclude $< -o $@ -L$(PKG) -llbm_mi355x -Wl,-rpath,'$$ORIGIN/$(PKG)' -Wl,-rpath,/opt/rocm/lib
 
-tools: tools/kbench tools/layout_bench tools/exact_math_check
+tools: tools/kbench tools/layout_bench tools/exact_math_check tools/oob_store_order
+
+tools/oob_store_order: tools/oob_store_order.hip
+	$(HIPCC) -O2 --offload-arch=gfx950 -Wno-unused-value $< -o $@
 
 tools/layout_bench: tools/layout_bench.hip
 	$(HIPCC) $(HIPFLAGS) $< -o $@
@@ -49,4 +52,4 @@ check:
 .PHONY: all lib tools oracle check clean
 
 clean:
-	rm -f $(EXE) $(LIB) tools/kbench tools/layout_bench tools/exact_math_check
+	rm -f $(EXE) $(LIB) tools/kbench tools/layout_bench tools/exact_math_check tools/oob_store_order
