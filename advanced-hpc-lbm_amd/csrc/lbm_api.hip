@@ -220,6 +220,8 @@ struct lbm_ctx {
   long rpartials_cap = 0;      // in steps
   int rpartials_tiles = 0;     // tiles per step it was sized for
   uint32_t* rabort = nullptr;  // device abort word of the resident kernel
+  int regtile_async = 1;       // lbm_regtile, R > 1: the loop's mail issued and waited for by hand (counted vmcnt), granules sent at once
+                               // (0: the round-2 loop, compiler-scheduled loads and stores; R = 1 always runs that one)
   uint32_t rtag = 1;           // next unused mailbox tag (0 = never written); never goes back except when the mailboxes are cleared
   bool resident_broken = false;   // the resident kernel cannot run here (not every tile resident, set-up failed, or a run
                                   // gave up): stay with the streaming kernels
@@ -763,6 +765,7 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
     else (void)hipGetLastError();
     const char* e = getenv("LBM_ENGINE");
     if (e) c->engine = (atoi(e) == 0 || atoi(e) == 1 || atoi(e) == 3) ? atoi(e) : 0;
+    if ((e = getenv("LBM_REGTILE_ASYNC"))) c->regtile_async = atoi(e) ? 1 : 0;
     if (!exchanging && c->slabs.size() == 1) plan_regtile(c);
     // Four steps per pass (lbm_march) where its strips and chunks fill the chip: measured 1.5-1.6x
     // lbm_sweep2 from 2048^2 up (194 / 226 / 238 GLUPS at 2048^2 / 4096^2 / 8192^2 against 129 / 146 /
@@ -1846,8 +1849,11 @@ bool plan_regtile(lbm_ctx* c) {
 
 // The instantiation of lbm_regtile for a tiling and flavour (dbg: the LBM_RESIDENT_DEBUG timing experiments, R = 4 only).
 typedef void (*regtile_fn)(const lbm::RegTileArgs);
-regtile_fn regtile_kernel(int r, bool fast, int dbg, bool trace) {
-  constexpr int NW_ = lbm::kResDebugNoWait, NS_ = lbm::kResDebugNoSend;
+regtile_fn regtile_kernel(int r, bool fast, int dbg, bool trace, bool async) {
+  constexpr int NW_ = lbm::kResDebugNoWait, NS_ = lbm::kResDebugNoSend, AS_ = lbm::kRegAsync;
+  if (async && dbg == 0 && !trace && r == 4) return fast ? lbm::lbm_regtile<4, AS_ | 1> : lbm::lbm_regtile<4, AS_>;
+  if (async && dbg == 0 && !trace && r == 2) return fast ? lbm::lbm_regtile<2, AS_ | 1> : lbm::lbm_regtile<2, AS_>;
+  if (async && trace && r == 4) return lbm::lbm_regtile<4, AS_ | 2048 | 1>;
   if (r == 4 && dbg == 1) return lbm::lbm_regtile<4, NW_>;
   if (r == 4 && dbg == 2) return lbm::lbm_regtile<4, NW_ | NS_>;
   if (r == 4 && dbg == 3) return lbm::lbm_regtile<4, NW_ | NS_ | 256>;
@@ -1900,7 +1906,7 @@ int run_regtile(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
   const unsigned shm = (unsigned)lbm::regtile_lds_bytes(t.nw, t.r);
   const char* dbg = getenv("LBM_RESIDENT_DEBUG");   // timing experiments (wrong results): see lbm_regtile.hip.h
   static const bool want_stats = getenv("LBM_REGTILE_STATS") != nullptr;   // development: missed polls per run, and a trace
-  const regtile_fn fn = regtile_kernel(t.r, fast, dbg ? atoi(dbg) : 0, want_stats && getenv("LBM_REGTILE_TRACE"));
+  const regtile_fn fn = regtile_kernel(t.r, fast, dbg ? atoi(dbg) : 0, want_stats && getenv("LBM_REGTILE_TRACE"), c->regtile_async != 0);
   if (c->tplan.bpc == 0) {                             // first run of this tiling: is every tile resident at once?
     const int n = regtile_prepare(c, fn, s.dev, (int)block.x, shm);
     c->tplan.bpc = (n < 0) ? -1 : n;
@@ -1949,7 +1955,7 @@ int run_regtile(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
   a.fault = getenv("LBM_REGTILE_FAULT") ? 1 : 0;   // (tests: a tile that never starts)
   a.stats = nullptr;
   static unsigned long long* stats_buf = nullptr;
-  constexpr size_t kStatsWords = 4 + 16 * 4 * 16;
+  constexpr size_t kStatsWords = 4 + 16 * 4 * 16 + 72;    // (+ the first wave that gave up: lbm_regtile.hip.h, await)
   if (want_stats) {
     if (!stats_buf) HIPC(hipMalloc((void**)&stats_buf, kStatsWords * 8));
     unsigned long long head[4] = {0, 0, (unsigned long long)(getenv("LBM_REGTILE_TRACE_TILE") ? atoi(getenv("LBM_REGTILE_TRACE_TILE")) : ntiles / 2 + t.ntx / 2),
@@ -1976,9 +1982,14 @@ int run_regtile(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
     HIPC(hipMemcpy(st.data(), stats_buf, kStatsWords * 8, hipMemcpyDeviceToHost));
     fprintf(stderr, "lbm_regtile: %d steps, %d waves: %llu waits found their mail missing (%.3f per wave and step), %llu extra fetches\n",
             nsteps, ntiles * t.nw, st[0], (double)st[0] / ((double)nsteps * ntiles * t.nw), st[1]);
+    if (st[1028] != 0) {
+      fprintf(stderr, "lbm_regtile: the first wave to give up: tile %llu (of %d x %d) wave %llu row %llu, waiting for tag %llu (run's tag0 %u); tags it holds, lane: couriers / edge row\n",
+              st[1028] - 1, t.ntx, t.nty, st[1029], st[1030], st[1031], a.tag0);
+      for (int l : {0, 1, 2, 3, 31, 60, 61, 62, 63}) fprintf(stderr, "   lane %2d: %llu / %llu\n", l, st[1032 + l] >> 32, st[1032 + l] & 0xffffffffull);
+    }
     if (getenv("LBM_REGTILE_TRACE")) {
       unsigned long long t0 = ~0ull;
-      for (size_t i = 4; i < kStatsWords; ++i) if (st[i] && st[i] < t0) t0 = st[i];
+      for (size_t i = 4; i < 4 + 16 * 4 * 16; ++i) if (st[i] && st[i] < t0) t0 = st[i];
       fprintf(stderr, "trace of tile %llu from step %llu (shader clocks / 100 since the first stamp; slots: barrier | per row: start, mail, done | end)\n", st[2], st[3]);
       for (int ww = 0; ww < t.nw; ++ww)
         for (int q = 0; q < 4; ++q) {
@@ -2568,6 +2579,12 @@ extern "C" int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     if (value == 3) { c->resident_broken = false; c->resident_why[0] = 0; if (c->tplan.bpc < 0) c->tplan.bpc = 0; }
     return LBM_OK;
   }
+  if (!strcmp(key, "regtile_async")) {
+    if (value != 0 && value != 1) return fail(LBM_EINVAL, "regtile_async must be 0 or 1");
+    c->regtile_async = (int)value;
+    c->tplan.bpc = c->tplan.bpc < 0 ? c->tplan.bpc : 0;     // (another instantiation: ask about its residency again)
+    return LBM_OK;
+  }
   if (!strcmp(key, "regtile")) {   // rows per tile * 10 + rows per wave
     const int ty = (int)(value / 10), r = (int)(value % 10);
     if (c->exchange != 0 || c->slabs.size() != 1 || !regtile_ok(c, ty, r))
@@ -2614,6 +2631,7 @@ extern "C" int lbm_get_info(const lbm_ctx* c, const char* key, double* value) {
   if (!strcmp(key, "regtile_blocks_per_cu")) { *value = c->tplan.bpc; return LBM_OK; }              // occupancy answer (0: not asked yet)
   if (!strcmp(key, "compute_units")) { *value = c->ncu; return LBM_OK; }
   if (!strcmp(key, "regtile")) { *value = c->tplan.ty * 10.0 + c->tplan.r; return LBM_OK; }
+  if (!strcmp(key, "regtile_async")) { *value = c->regtile_async; return LBM_OK; }
   if (!strcmp(key, "exchange")) { *value = c->exchange; return LBM_OK; }
   if (!strcmp(key, "pitch")) { *value = c->slabs[0].pitch; return LBM_OK; }
   if (!strcmp(key, "hbm_bytes")) {

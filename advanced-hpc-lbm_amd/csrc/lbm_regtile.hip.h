@@ -50,6 +50,7 @@ namespace lbm {
 constexpr long long kResidentTimeoutTicks = 100000000LL;       // a wait for mail gives up after 1 s of the 100 MHz wall clock
 // timing experiments only (wrong results): LBM_RESIDENT_DEBUG=1 never waits for a tag, 2 also sends nothing
 constexpr int kResDebugNoWait = 64, kResDebugNoSend = 128;
+constexpr int kRegAsync = 4096;   // lbm_regtile: mail loads / stores of the loop as inline asm with counted s_waitcnt vmcnt(N)
 typedef __attribute__((address_space(1))) unsigned int gu32;
 
 // Per-step sums of a whole-run launch: partials[step][tile] -> sums[step] (double, fixed order), one wave per step; also
@@ -116,6 +117,8 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
   constexpr bool DBG_NOWAIT = (MODE & kResDebugNoWait) != 0, DBG_NOSEND = (MODE & kResDebugNoSend) != 0, DBG_NOLOAD = (MODE & 256) != 0;
   constexpr bool DBG_DROP = (MODE & 512) != 0, DBG_PLAIN = (MODE & 1024) != 0;
   constexpr bool TRACE = (MODE & 2048) != 0;     // development: time stamps of one tile's waves (LBM_REGTILE_TRACE)
+  // The mail of the loop issued and waited for BY HAND (R > 1): see "the asynchronous loop" below
+  constexpr bool ASYNC = (MODE & kRegAsync) != 0 && R > 1;
   static_assert(R == 1 || R == 2 || R == 4, "rows per wave");
   // LDS (dynamic, regtile_lds_bytes(nw, R)): edge rows between the waves of the tile [parity][wave][6][64]; the
   // populations no other row ever pulls from -- planes 0, 1, 3 of every row, [wave][R][3][64]: a row's own update is
@@ -196,13 +199,13 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
   // what a row hands to the neighbouring tiles, from the state in f (pb = parity x BOX)
   auto send_row = [&](auto rc, uint32_t tag, unsigned pb, const float (&q)[9]) {   // q = the row's nine populations
     constexpr int r = decltype(rc)::value;
+    const float e1 = q[1], e5 = q[5], e8 = q[8], w3 = q[3], w6 = q[6], w7 = q[7];
+    const bool wl = lane == 0;
+    const float v0 = wl ? w3 : e1, v1 = wl ? w6 : e5, v2 = wl ? w7 : e8;
     if (r == 0 && first)             // the tile's bottom row enters the tile below through ITS north inbox
       send(lane16, box(tS) + oN + pb, q[4], q[7], q[8], tag);
     if (r == R - 1 && last)
       send(lane16, box(tN) + oS + pb, q[2], q[5], q[6], tag);
-    const float e1 = q[1], e5 = q[5], e8 = q[8], w3 = q[3], w6 = q[6], w7 = q[7];
-    const bool wl = lane == 0;
-    const float v0 = wl ? w3 : e1, v1 = wl ? w6 : e5, v2 = wl ? w7 : e8;
     if (edge_lane) send(ew_voff, pb + 16u * r, v0, v1, v2, tag);
     // the tile's corners: the same granule is row -1 / row TY of the diagonal tile's inbox
     if (r == R - 1 && last && edge_lane) send(cn_voff, pb, v0, v1, v2, tag);
@@ -275,6 +278,19 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
       }
       if (wall_clock64() - t0 > kResidentTimeoutTicks ||
           __hip_atomic_load((gu32*)a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        // development (LBM_REGTILE_STATS): the FIRST wave that gives up (not one that follows the abort word) says where it
+        // stood -- stats[1028 + 0..]: 1 + tile, wave, row, tag wanted, then per lane the tags it holds (couriers' granule; the
+        // row below / above the tile)
+        if (a.stats != nullptr && wall_clock64() - t0 > kResidentTimeoutTicks) {
+          unsigned long long* d = a.stats + 1028;
+          unsigned long long claimed = 0ull;
+          if (lane == 0) claimed = atomicCAS(d, 0ull, (unsigned long long)(tile + 1));
+          claimed = __shfl(claimed, 0, 64);
+          if (claimed == 0ull) {
+            if (lane == 0) { d[1] = (unsigned long long)w; d[2] = (unsigned long long)decltype(rc)::value; d[3] = want; }
+            d[4 + lane] = ((unsigned long long)m.g.w << 32) | (unsigned long long)m.e.w;
+          }
+        }
         __hip_atomic_store((gu32*)a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *lds_abort = 1u;      // (this wave carries on with what it has; everybody leaves together behind the next barrier)
         return;
@@ -290,13 +306,21 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
 
   if (a.fault != 0 && tile == 0) return;
   // ---- state 0: loaded, and sent row by row like every other state
+  // (every row's nine loads are issued before any row is used: with a row's sends between them the loads of the next row
+  // wait behind the compiler's drain for this row's -- R round trips to memory instead of one, 2-3 us each, paid per RUN)
+  float q0[R][9];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const long o = (long)(gy0 + r) * a.pitch + gx;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) q0[r][k] = a.src[k * a.plane + o];
+    blk[r] = a.blocked[o] != 0;
+  }
   auto first_state = [&](auto rc) {
     constexpr int r = decltype(rc)::value;
-    const long o = (long)(gy0 + r) * a.pitch + gx;
     float q[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) q[k] = a.src[k * a.plane + o];
-    blk[r] = a.blocked[o] != 0;
+    for (int k = 0; k < 9; ++k) q[k] = q0[r][k];
     if (gy0 + r == a.accel_row) accelerate_cell(q, blk[r], a.a1, a.a2);   // accelerate phase of the first step
     f[r][2] = q[2]; f[r][4] = q[4]; f[r][5] = q[5]; f[r][6] = q[6]; f[r][7] = q[7]; f[r][8] = q[8];
     if constexpr (OWN_LDS) { own[(r * 3 + 0) * 64] = q[0]; own[(r * 3 + 1) * 64] = q[1]; own[(r * 3 + 2) * 64] = q[3]; }
@@ -307,6 +331,250 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
   if constexpr (R > 1) first_state(I1{});
   if constexpr (R > 2) { first_state(I2{}); first_state(I3{}); }
   publish_lds(0);
+
+  // ============================================================================================================
+  // The asynchronous loop (R > 1, MODE & kRegAsync).  The loop above this point's successor -- mail fetched one row
+  // ahead, a row's granules sent only behind the wait for the next row's mail -- spends a step on four load latencies:
+  // a hand-off takes ~2000 cycles, a row's arithmetic ~1000, and hipcc turns every wait for a load behind a branch with
+  // a store in it into s_waitcnt vmcnt(0), store acknowledgements (~1500 cycles) included.  Here the loop's mail traffic
+  // is inline asm the compiler neither counts nor waits for (cdna_hip_programming.md 5.7, form (ii)):
+  //   * every wave issues THE SAME vector-memory operations per row, unconditionally -- lanes and waves an operation does
+  //     not concern carry an offset beyond the descriptor's range (loads answer zeros, stores are dropped; such operations
+  //     keep their place in the wave's vmcnt queue: tools/oob_store_order, measured) -- so the number of operations
+  //     younger than a given fetch is a compile-time constant and the wait for it is a COUNTED s_waitcnt vmcnt(N);
+  //   * a row's granules leave right behind its arithmetic, its mail is requested D = R/2 rows ahead: the granule is
+  //     R - D row-times old when it is asked for and has D row-times to arrive;
+  //   * per row i (in the wave's sweep order):  wait(mail i) -> check tags (else: fetch again, drain, bounded) -> unpack
+  //     -> fetch(mail i + D) -> arithmetic -> stores of row i.  Operations younger than fetch(i) at wait(i):
+  //     the loads of fetch(i+1 .. i+D-1) and the stores of rows i-D .. i-1:  N(i) = sum L(i+k), k < D, + sum S(i-k), k <= D,
+  //     with L = 2 loads for a band's first / last row (couriers + the row below / above the tile), 1 otherwise, and
+  //     S = 3 stores for those rows (east/west granule, north/south granules, corner granule), 1 otherwise.
+  //     The first step waits with vmcnt(0) (its queue holds the prologue, not the steady pattern); the last step still
+  //     fetches "the next step's" mail (unused), so that its own waits see the steady pattern; unknown extra operations
+  //     (the step sums' store of wave 0) only make a counted wait stricter.  A miss drains the queue (vmcnt(0)), after
+  //     which counted waits are trivially satisfied until the pattern has refilled.
+  if constexpr (ASYNC) {
+    // Where the mail lands: in ordinary registers the loads name as asm outputs ("=v") and a wait statement takes as
+    // read-write operands ("+v") before their first use -- which pins the ORDER of issue, wait and use, not the registers:
+    // hipcc may still copy such a value while it is in flight (it did: with the two sweep directions as branches inside ONE
+    // step loop it merged their slots with v_mov at the join, of registers whose load had not landed).  So each direction
+    // gets a step loop of its own (no join inside the loop), and the build is AUDITED: tools/audit_regtile_isa.py walks the
+    // ISA from every asm load to the wait that retires it and fails on any instruction in between that touches the
+    // destination registers (run by tests/test_abi.py).  (Accumulator registers named in the asm text would be out of the
+    // compiler's reach, but a kernel that uses them gets the register file split 64 / 64.)
+    // rows a row's mail is requested ahead.  R / 2 looked right on paper (the granule R/2 row-times old when asked for, R/2
+    // row-times to arrive) and lost: a third of the early requests found yesterday's tag (1.28 misses per wave and step at
+    // R = 4 against 0.26 one row ahead -- neighbouring tiles are not in lockstep to a row) and a miss costs a drain and a
+    // second round trip: 1024x1024 5.24 us per step against 4.15 (both in one call, profiles/r03_regtile_async.log)
+    constexpr int D = 1;
+    struct Slot { rt_u4 g, e; };
+    const unsigned boxS = __builtin_amdgcn_readfirstlane(box(tS) + oN), boxN = __builtin_amdgcn_readfirstlane(box(tN) + oS);
+    const unsigned ew_m = edge_lane ? ew_voff : OOB;                       // east / west granule: lanes 0 and 63
+    const unsigned cs_m = (first && edge_lane) ? cs_voff : OOB, cn_m = (last && edge_lane) ? cn_voff : OOB;   // corners
+    auto aload = [&](rt_u4& dst, unsigned voff, unsigned soff) {
+      const auto rs = rsrc;
+      // (no s_nop in front: descriptor and scalar offset come from scalar-ALU code, never fresh from a vector instruction --
+      // tools/audit_regtile_isa.py checks the five instructions in front of every one of these for a VALU write to them)
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen sc1" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+    };
+    auto astore = [&](unsigned voff, unsigned soff, float v0, float v1, float v2, uint32_t tag) {
+      rt_u4 g;
+      g.x = __float_as_uint(v0); g.y = __float_as_uint(v1); g.z = __float_as_uint(v2); g.w = tag;
+      const auto rs = rsrc;
+      asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 1" :: "v"(g), "v"(voff), "s"(rs), "s"(soff) : "memory");
+    };
+    auto afetch = [&](auto rc, unsigned pbx, Slot& m) {
+      constexpr int r = decltype(rc)::value;
+      aload(m.g, rv_voff, mybox + pbx + 16u * r);
+      if constexpr (r == 0) aload(m.e, first_voff, mybox + oS + pbx);
+      else if constexpr (r == R - 1) aload(m.e, last_voff, mybox + oN + pbx);
+    };
+    // all but the N youngest operations are done: the slot's registers hold its granules ("retire" marks the statement for the audit)
+    auto aretire = [&](auto rc, auto nc, Slot& m) {
+      constexpr int r = decltype(rc)::value, N = decltype(nc)::value;
+      if constexpr (r == 0 || r == R - 1) asm volatile("s_waitcnt vmcnt(%2) ; retire %0 %1" : "+v"(m.g), "+v"(m.e) : "n"(N));
+      else asm volatile("s_waitcnt vmcnt(%1) ; retire %0" : "+v"(m.g) : "n"(N));
+    };
+    auto aarrived = [&](auto rc, const Slot& m, uint32_t want) {
+      constexpr int r = decltype(rc)::value;
+      bool ok = true;
+      if (courier) ok = m.g.w == want;
+      if ((r == 0 && first) || (r == R - 1 && last)) ok = ok && m.e.w == want;
+      return __all(ok) != 0;
+    };
+    auto aslow = [&](auto rc, unsigned pbx, uint32_t want, Slot& m) {       // the mail was not there: fetch again, drained, bounded
+      const long long t0 = wall_clock64();
+      ++nmiss;
+      for (;;) {
+        __builtin_amdgcn_s_sleep(1);
+        ++nspin;
+        afetch(rc, pbx, m);
+        aretire(rc, std::integral_constant<int, 0>{}, m);
+        if (aarrived(rc, m, want)) return;
+        if (wall_clock64() - t0 > kResidentTimeoutTicks ||
+            __hip_atomic_load((gu32*)a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          __hip_atomic_store((gu32*)a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          *lds_abort = 1u;
+          return;
+        }
+      }
+    };
+    bool aborted = false;
+    // the whole step loop for one sweep direction
+    auto run = [&](auto up_c) {
+      constexpr bool UP = decltype(up_c)::value;
+      Slot slot[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) { slot[d].g = rt_u4{0u, 0u, 0u, 0u}; slot[d].e = slot[d].g; }
+      // prologue: the mail of the first D rows of step 1 (state 0, parity 0)
+      {
+        unsigned pb0 = 0u;
+        asm volatile("" : "+s"(pb0));
+        afetch(std::integral_constant<int, UP ? 0 : R - 1>{}, pb0, slot[0]);
+        if constexpr (D > 1) afetch(std::integral_constant<int, UP ? 1 : R - 2>{}, pb0, slot[1]);
+      }
+      for (int s = 1; s <= a.nsteps; ++s) {
+        int par = (s - 1) & 1;
+        asm volatile("" : "+s"(par));
+        const unsigned pb = (unsigned)par * BOX, pbn = BOX - pb;
+        const uint32_t want = a.tag0 + (uint32_t)(s - 1), tagn = want + 1u;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave's edge rows of state s-1 are in LDS
+        if (*lds_abort != 0u) { aborted = true; break; }
+        stamp(s, 0);
+        if (s > 1 && tid < 64) {                       // speed sum of step s-1
+          float v = (lane < nw) ? red[par * 16 + lane] : 0.f;
+          v = wave_sum(v);
+          if (tid == 0) a.partials[(long)(s - 2) * nt + tile] = v;
+        }
+        const bool laststep = (s == a.nsteps), firststep = (s == 1);
+        float sp = 0.f;
+        float sv[3] = {0.f, 0.f, 0.f};               // going up: old planes 2,5,6 of the row just overwritten; going down: 4,7,8
+        auto one = [&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          constexpr int r = UP ? i : R - 1 - i;
+          using RC = std::integral_constant<int, r>;
+          Slot& m = slot[i % D];
+          __builtin_amdgcn_s_setprio(3 - (i * 4) / R);
+          stamp(s, 1 + 3 * i);
+          // ---- wait for this row's mail: all but the N(i) youngest operations are done
+          constexpr int N = [] { int n = 0; for (int k = 1; k < D; ++k) { int j = (((i + k) % R) + R) % R; n += (j == 0 || j == R - 1) ? 2 : 1; }
+                                  for (int k = 1; k <= D; ++k) { int j = (((i - k) % R) + R) % R; n += (j == 0 || j == R - 1) ? 3 : 1; } return n; }();
+          // (ONE statement names the slot's registers on every path: two of them, one per branch, and hipcc gives each its own
+          // registers and copies the in-flight slot from one set to the other at the loop's back edge)
+          if (firststep) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          aretire(RC{}, std::integral_constant<int, N>{}, m);
+          if (!aarrived(RC{}, m, want)) aslow(RC{}, pb, want, m);
+          stamp(s, 2 + 3 * i);
+          // ---- unpack: couriers -> edge lanes; the row below / above the tile
+          const float m0 = __uint_as_float(m.g.x);
+          const float m1w = rt_row_shl<1>(m.g.y), m1e = rt_row_shr<1>(m.g.y);
+          const float m2w = rt_row_shl<2>(m.g.z), m2e = rt_row_shr<2>(m.g.z);
+          float lo[3], hi[3], keep[3];
+          if constexpr (UP) {
+            constexpr int ra = (r < R - 1) ? r + 1 : r;
+            lo[0] = sv[0]; lo[1] = sv[1]; lo[2] = sv[2];
+            hi[0] = f[ra][4]; hi[1] = f[ra][7]; hi[2] = f[ra][8];
+            keep[0] = f[r][2]; keep[1] = f[r][5]; keep[2] = f[r][6];
+          } else {
+            constexpr int rb = (r > 0) ? r - 1 : r;
+            hi[0] = sv[0]; hi[1] = sv[1]; hi[2] = sv[2];
+            lo[0] = f[rb][2]; lo[1] = f[rb][5]; lo[2] = f[rb][6];
+            keep[0] = f[r][4]; keep[1] = f[r][7]; keep[2] = f[r][8];
+          }
+          if (r == 0) {
+            if (first) { lo[0] = __uint_as_float(m.e.x); lo[1] = __uint_as_float(m.e.y); lo[2] = __uint_as_float(m.e.z); }
+            else {
+              const float* q = lds + ((par * nw + (w - 1)) * 6 + 3) * 64 + lane;
+              lo[0] = q[0]; lo[1] = q[64]; lo[2] = q[128];
+            }
+          }
+          if (r == R - 1) {
+            if (last) { hi[0] = __uint_as_float(m.e.x); hi[1] = __uint_as_float(m.e.y); hi[2] = __uint_as_float(m.e.z); }
+            else {
+              const float* q = lds + ((par * nw + (w + 1)) * 6) * 64 + lane;
+              hi[0] = q[0]; hi[1] = q[64]; hi[2] = q[128];
+            }
+          }
+          // ---- the mail of the row D positions on (this step's, or the next step's first rows: always issued, see above)
+          {
+            constexpr int j = i + D;
+            constexpr int rj = UP ? (j % R) : R - 1 - (j % R);
+            if constexpr (j < R) afetch(std::integral_constant<int, rj>{}, pb, m);
+            else afetch(std::integral_constant<int, rj>{}, pbn, m);
+          }
+          // ---- the row
+          float p[9];
+          float c0, c1, c3;
+          if constexpr (OWN_LDS) { c0 = own[(r * 3 + 0) * 64]; c1 = own[(r * 3 + 1) * 64]; c3 = own[(r * 3 + 2) * 64]; }
+          else { c0 = f[r][0]; c1 = f[r][1]; c3 = f[r][3]; }
+          p[0] = c0;
+          p[1] = rt_west(m0, c1);
+          p[3] = rt_east(m0, c3);
+          p[2] = lo[0];
+          p[5] = rt_west(m1w, lo[1]);
+          p[6] = rt_east(m1e, lo[2]);
+          p[4] = hi[0];
+          p[7] = rt_east(m2e, hi[1]);
+          p[8] = rt_west(m2w, hi[2]);
+          sp += collide_cell<FAST, true>(p, blk[r], a.omega);
+          if (gy0 + r == a.accel_row && !laststep) accelerate_cell(p, blk[r], a.a1, a.a2);
+          f[r][2] = p[2]; f[r][4] = p[4]; f[r][5] = p[5]; f[r][6] = p[6]; f[r][7] = p[7]; f[r][8] = p[8];
+          if constexpr (OWN_LDS) { own[(r * 3 + 0) * 64] = p[0]; own[(r * 3 + 1) * 64] = p[1]; own[(r * 3 + 2) * 64] = p[3]; }
+          else { f[r][0] = p[0]; f[r][1] = p[1]; f[r][3] = p[3]; }
+          sv[0] = keep[0]; sv[1] = keep[1]; sv[2] = keep[2];
+          // ---- its granules, at once (S(i) stores, the same in every wave)
+          {
+            const bool wl = lane == 0;
+            const float v0 = wl ? p[3] : p[1], v1 = wl ? p[6] : p[5], v2 = wl ? p[7] : p[8];
+            astore(ew_m, pbn + 16u * r, v0, v1, v2, tagn);
+            if constexpr (r == 0) {
+              astore(first_voff, boxS + pbn, p[4], p[7], p[8], tagn);
+              astore(cs_m, pbn, v0, v1, v2, tagn);
+            }
+            if constexpr (r == R - 1) {
+              astore(last_voff, boxN + pbn, p[2], p[5], p[6], tagn);
+              astore(cn_m, pbn, v0, v1, v2, tagn);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);           // one row at a time
+          stamp(s, 3 + 3 * i);
+        };
+        one(std::integral_constant<int, 0>{});
+        one(std::integral_constant<int, 1>{});
+        if constexpr (R > 2) { one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{}); }
+        if (!laststep) publish_lds(s & 1);
+        stamp(s, 13);
+        sp = wave_sum(sp);
+        if (lane == 0) red[(s & 1) * 16 + w] = sp;
+      }
+      // nothing of the loop's mail is in flight beyond this point (the slots' last fetches are never used: retire them)
+#pragma unroll
+      for (int d = 0; d < D; ++d) asm volatile("s_waitcnt vmcnt(0) ; retire %0 %1" : "+v"(slot[d].g), "+v"(slot[d].e));
+    };
+    if (!down) run(std::true_type{}); else run(std::false_type{});
+    __syncthreads();
+    if (a.stats != nullptr && lane == 0) { atomicAdd(a.stats, (unsigned long long)nmiss); atomicAdd(a.stats + 1, (unsigned long long)nspin); }
+    if (aborted || *lds_abort != 0u) return;          // (the host repeats the run from the untouched source lattice)
+    {
+      int gyq = gy0, gxq = gx;
+      asm volatile("" : "+v"(gyq), "+v"(gxq));
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const long o = (long)(gyq + r) * a.pitch + gxq;
+        if constexpr (OWN_LDS) { a.dst[o] = own[(r * 3 + 0) * 64]; a.dst[a.plane + o] = own[(r * 3 + 1) * 64]; a.dst[3 * a.plane + o] = own[(r * 3 + 2) * 64]; }
+        else { a.dst[o] = f[r][0]; a.dst[a.plane + o] = f[r][1]; a.dst[3 * a.plane + o] = f[r][3]; }
+#pragma unroll
+        for (int k = 2; k < 9; ++k)
+          if (k != 3) a.dst[k * a.plane + o] = f[r][k];
+      }
+    }
+    if (tid < 64) {
+      float v = (lane < nw) ? red[(a.nsteps & 1) * 16 + lane] : 0.f;
+      v = wave_sum(v);
+      if (tid == 0) a.partials[(long)(a.nsteps - 1) * nt + tile] = v;
+    }
+    return;
+  }
 
   Mail pre;                                        // the mail of a step's first row: in flight across the barrier
   blank(pre);

@@ -65,3 +65,17 @@ def test_product_never_touches_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "lbm_oracle" not in text and "liblbm_oracle" not in text, f
                 assert not re.search(r"^\s*(import|from)\s+oracle", text, flags=re.M), f
+
+
+def test_hand_issued_mail_loads_of_the_register_tile_kernel_are_left_alone_by_the_compiler():
+    """lbm_regtile's asynchronous loop issues its mail loads as inline asm and retires them with counted waits; the
+    destination registers belong to the compiler from the end of the asm statement although the data lands later
+    (cdna_hip_programming.md 5.7).  tools/audit_regtile_isa.py compiles the library's device code and walks the ISA from
+    every such load, along every path, to the wait that retires it: no instruction in between may touch the destination
+    registers, no scratch, no AGPR traffic, no vector-written scalar operand within five instructions of an asm memory
+    operation.  (Runs without a GPU: hipcc cross-compiles.)"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_regtile_isa.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 finding(s)" in r.stdout and "asm loads audited" in r.stdout

@@ -1405,3 +1405,30 @@ def test_rccl_contexts_march_by_default_where_the_slab_fills_the_chip(gpu):
             assert np.array_equal(st_a.view(np.uint32), st_b.view(np.uint32)), (nx, ny)
     finally:
         del os.environ["LBM_FORCE_EXCHANGE"]
+
+
+@pytest.mark.parametrize("tile,nx,ny,steps", [
+    ((4, 2), 64, 4, [1]), ((4, 2), 64, 8, [5, 2]), ((8, 4), 64, 8, [5, 2]),        # one tile column: a tile is its own east and west neighbour
+    ((4, 2), 128, 16, [7]), ((8, 2), 128, 16, [7, 1]), ((32, 4), 192, 96, [10]), ((8, 4), 256, 256, [9]), ((16, 2), 256, 256, [9, 4]),
+    ((64, 4), 1024, 1024, [21]), ((32, 4), 1024, 1024, [9]), ((32, 2), 1024, 512, [11]),
+])
+def test_register_tile_asynchronous_loop_equals_single_step_kernel(gpu, tile, nx, ny, steps):
+    """lbm_regtile with its loop's mail issued and waited for by hand (regtile_async 1: inline-asm sc1 loads and stores, the
+    same operations in every wave so that the waits are counted s_waitcnt vmcnt(N), granules sent right behind a row's
+    arithmetic and requested R/2 rows ahead) against the one-step kernel: bit-identical lattice, av_vels within summation
+    order; several runs on one context (tags carry on), tilings with one and two blocks per CU."""
+    L = gpu
+    p, ob, cells = _random_case(L, nx, ny, 5)
+    with L.Lattice(p, ob, cells) as a:
+        a.set_option("time_block", 1)
+        av_a = np.concatenate([a.run(n) for n in steps])
+        st_a = a.read_state()
+    with L.Lattice(p, ob, cells) as b:
+        b.set_option("regtile", tile[0] * 10 + tile[1])
+        b.set_option("regtile_async", 1)
+        b.set_option("engine", 3)
+        av_b = np.concatenate([b.run(n) for n in steps])
+        assert b.info("engine_last") == 3 and b.info("regtile_async") == 1
+        st_b = b.read_state()
+    assert np.array_equal(st_a.view(np.uint32), st_b.view(np.uint32))
+    assert np.allclose(av_a, av_b, rtol=2e-6, atol=0)

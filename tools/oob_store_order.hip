@@ -83,6 +83,49 @@ __global__ void probe(const unsigned* src, unsigned* sink, unsigned nbytes_src, 
   if (misses) atomicAdd(miss, misses);
 }
 
+// Second question (the masked-store hang of lbm_regtile's round-2 loop, bisected in round 3 to "north / south store masked
+// AND east / west store masked": in a wave that is neither the tile's first nor its last, an ALL-lanes-out-of-range store
+// directly in front of a store with two lanes in range): is a buffer store that follows an all-out-of-range store
+// back to back performed?  GAP = s_nop count between the two (-1: none).  The host reads the sink back.
+template <int GAP, int ORDER>
+__global__ void probe_pair(unsigned* sink, unsigned nbytes_sink, int iters) {
+  const int lane = threadIdx.x & 63;
+  const unsigned gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const auto rd = __builtin_amdgcn_make_buffer_rsrc((void*)sink, 0, (int)nbytes_sink, 0x00020000);
+  const unsigned OOB = 0x80000000u;
+  for (int i = 0; i < iters; ++i) {
+    const unsigned slot = (gw * (unsigned)iters + (unsigned)i) * 2u;            // two granules per (wave, iteration): lanes 0 and 63
+    const unsigned in_off = (lane == 0) ? slot * 16u : (lane == 63) ? (slot + 1u) * 16u : OOB;
+    u4 val = {0xabcd0000u + (unsigned)i, gw, (unsigned)lane, 0x600dbeefu};
+    u4 junk = {1u, 2u, 3u, 4u};
+    if (ORDER == 0) {          // all-out-of-range store FIRST, the real one right behind it
+      if (GAP < 0) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1\n\tbuffer_store_dwordx4 %3, %4, %2, 0 offen sc1\n\ts_nop 1"
+                                :: "v"(junk), "v"(OOB), "s"(rd), "v"(val), "v"(in_off) : "memory");
+      else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1\n\ts_nop %5\n\tbuffer_store_dwordx4 %3, %4, %2, 0 offen sc1\n\ts_nop 1"
+                        :: "v"(junk), "v"(OOB), "s"(rd), "v"(val), "v"(in_off), "n"(GAP < 0 ? 0 : GAP) : "memory");
+    } else {                   // the real one first, the all-out-of-range store right behind it
+      asm volatile("buffer_store_dwordx4 %3, %4, %2, 0 offen sc1\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen sc1\n\ts_nop 1"
+                   :: "v"(junk), "v"(OOB), "s"(rd), "v"(val), "v"(in_off) : "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int GAP, int ORDER>
+static long run_pair(unsigned* sink, unsigned nsink, const char* what) {
+  const int blocks = 512, wpb = 8, iters = 64;
+  hipMemset(sink, 0, nsink);
+  hipLaunchKernelGGL((probe_pair<GAP, ORDER>), dim3(blocks), dim3(64 * wpb), 0, 0, sink, nsink, iters);
+  hipDeviceSynchronize();
+  const size_t n = (size_t)blocks * wpb * iters * 2;
+  std::vector<unsigned> h(n * 4);
+  hipMemcpy(h.data(), sink, n * 16, hipMemcpyDeviceToHost);
+  long lost = 0;
+  for (size_t g = 0; g < n; ++g) lost += (h[4 * g + 3] != 0x600dbeefu) ? 1 : 0;
+  printf("pair  %-70s: %ld of %zu in-range granules were NOT written\n", what, lost, n);
+  return lost;
+}
+
 int main() {
   const unsigned nsrc = 1u << 30, nsink = 1u << 24;   // 1 GiB of loads (well beyond the caches), 16 MiB sink
   unsigned *src, *sink, *miss;
@@ -116,6 +159,11 @@ int main() {
       if (c == 5 && m == 0) bad = 2;
     }
   }
+  run_pair<-1, 0>(sink, nsink, "all-out-of-range store, then (back to back) a store with lanes 0, 63 in range");
+  run_pair<0, 0>(sink, nsink, "the same with s_nop 0 between the two");
+  run_pair<1, 0>(sink, nsink, "the same with s_nop 1 between the two");
+  run_pair<4, 0>(sink, nsink, "the same with s_nop 4 between the two");
+  run_pair<-1, 1>(sink, nsink, "the store with lanes 0, 63 in range FIRST, the all-out-of-range store behind it");
   printf(bad == 1 ? "FAIL: the reference case itself misses -- the probe is wrong\n"
          : bad == 2 ? "FAIL: the control case shows no misses -- the probe cannot see an early wait\n" : "done\n");
   return bad;

@@ -29,5 +29,5 @@ for t in tilings:
             g, w = lat.last_run_ms()
             best = min(best, g)
         assert int(lat.info("engine_last")) == 3
-        print(f"dbg={os.environ.get('LBM_RESIDENT_DEBUG', '0')} {deck} regtile {int(lat.info('regtile'))} "
+        print(f"dbg={os.environ.get('LBM_RESIDENT_DEBUG', '0')} async={int(lat.info('regtile_async'))} {deck} regtile {int(lat.info('regtile'))} "
               f"{best * 1e3 / steps:.3f} us/step  {p.nx * p.ny * steps / best / 1e6:.1f} GLUPS", flush=True)
