@@ -744,6 +744,35 @@ bool slab_wave_pays(const lbm_ctx* c, int rows, int K = 8);
 int slab_wave_rows(const lbm_ctx* c, int ny_rows, int K = 8, int extra_waves = 0);
 double slab_wave_efficiency(const lbm_ctx* c, int ny_rows, int h, int K = 8, int extra_waves = 0);
 int march_rows_for(const lbm_ctx* c, int ny_rows);
+int wave_slots(const lbm_ctx* c, int K);
+
+// lbm_wave<8>: one or two columns per lane?  Each form is priced by what it does with a full chip -- 371 GLUPS with one
+// column (three waves per SIMD, 48 of 64 lanes delivered), 411 with two (two waves per SIMD, 112 of 128 delivered, the two
+// cells of a lane issued statement by statement) -- times the useful share of its wave-slot time with its best chunk
+// height on `rows` rows.  Measured in one call (profiles/r03_wave_two_columns.log): 8192^2 348 against 320 GLUPS (149-row
+// chunks: 4070 waves for 2 x 2048 slots), 6144^2 324 against 314, 4096^2 219 against 274 (too few waves for two rounds);
+// 8192-wide slabs of N = 2 / 4 / 8: 113 / 62.8 / 35.5 us per step against 119 / 66.7 / 37.4.  What the two-column form wants
+// is a chunk height that fills WHOLE rounds of its 2048 wave slots -- one round is as good as two: 4096^2 with 75-row chunks
+// (2035 waves) 321 GLUPS, with 74-row chunks (2072 waves: a second round for 24 of them) 208; lbm_march there: 278.
+// Sets c->wave_cols (unless the caller fixed it) and returns the predicted rate of the form chosen.
+double wave_pick_cols(lbm_ctx* c, int rows, int* rows_per_chunk) {
+  const bool fixed = getenv("LBM_WAVE_COLS") != nullptr;
+  double best = -1.0;
+  int best_c = c->wave_cols, best_h = 0;
+  for (int cols : {1, 2}) {
+    if (fixed && cols != c->wave_cols) continue;
+    if (cols == 2 && !(c->p.nx % 2 == 0 && c->p.nx >= 128)) continue;
+    const int was = c->wave_cols;
+    c->wave_cols = cols;
+    const int h = slab_wave_rows(c, rows, 8);
+    const double rate = (cols == 2 ? 411.0 : 371.0) * slab_wave_efficiency(c, rows, h, 8);
+    c->wave_cols = was;
+    if (rate > best) { best = rate; best_c = cols; best_h = h; }
+  }
+  c->wave_cols = best_c;
+  if (rows_per_chunk) *rows_per_chunk = best_h;
+  return best;
+}
 
 int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
   const bool exchanging = c->exchange != 0;
@@ -776,20 +805,18 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
       // (a function of the lattice and the number of slabs only: every rank decides alike)
       if (c->p.nx % 4 == 0 && c->p.nx >= lbm::MarchCfg<kMarchK>::W && c->p.ny / c->nranks >= 4 * kMarchK && p2p_march_pays(c)) c->time_block = 4;
       if (c->time_block == 4 && c->march_kernel != 0 && !getenv("LBM_MARCH_KERNEL")) {
-        // lbm_wave<6> with two columns per lane where its (fewer, fatter) waves fill a round of the chip: measured on the
-        // 8192-wide slabs of N = 2 / 4 / 8 (one GPU, ring of one, us per step): 115.2 / 63.6 / 35.3 against lbm_wave<8>'s
-        // 118.9 / 66.7 / 37.4 (profiles/r03_strong_scaling_proxy.log); else lbm_wave<8>, else lbm_march
+        // lbm_wave<8> (one or two columns per lane, whichever the model prices higher) where its waves fill a round of the chip
         const int rows = c->p.ny / c->nranks;
-        if (!getenv("LBM_WAVE_COLS") && c->p.nx % 2 == 0 && c->p.nx >= 128) {
-          c->wave_cols = 2;
-          if (slab_wave_pays(c, rows, 6)) c->time_block = 6; else c->wave_cols = 1;
-        }
-        if (c->time_block == 4 && slab_wave_pays(c, rows, 8)) c->time_block = 8;
+        wave_pick_cols(c, rows, nullptr);
+        if (slab_wave_pays(c, rows, 8)) c->time_block = 8; else c->wave_cols = 1;
       }
     } else
     if (!getenv("LBM_TIME_BLOCK") && c->time_block == 2 && exchanging && c->exchange == LBM_EXCHANGE_RCCL) {
       // RCCL halos (one process per GPU, or one process with a slab per GPU): lbm_wave<8> with ghost bands -- K rows of all
       // nine planes per direction per K steps -- where the smallest slab fills the chip's wave slots (every rank decides alike)
+      // (one column per lane: with the slab cut into an edge launch and an interior launch the two-column form's fewer, fatter
+      // waves measured behind -- ring of one, 8192-wide slabs of N = 1 / 2 / 4 / 8: 256 / 134 / 71.0 / 40.4 us per step against
+      // 219 / 122 / 68.3 / 39.1)
       if (c->march_kernel != 0 && slab_wave_pays(c, c->p.ny / c->nranks)) c->time_block = 8;
     } else
     if (!getenv("LBM_TIME_BLOCK") && c->time_block == 2 && exchanging) {
@@ -804,9 +831,12 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
       }
       if (!ok) { c->time_block = 2; c->march_slabs = -1; }
       else if (c->march_kernel != 0 && !getenv("LBM_MARCH_KERNEL")) {
+        int smallest = c->p.ny;
+        for (auto& s : c->slabs) smallest = std::min(smallest, s.nyl);
+        wave_pick_cols(c, smallest, nullptr);
         bool w8 = true;
         for (auto& s : c->slabs) w8 = w8 && slab_wave_pays(c, s.nyl);
-        if (w8) c->time_block = 8;
+        if (w8) c->time_block = 8; else c->wave_cols = 1;
       }
     } else
     if (!getenv("LBM_TIME_BLOCK") && c->time_block == 2) {
@@ -823,11 +853,12 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
       // 2048^2 201 / 230.
       if (c->time_block == 4 && c->march_kernel < 0 && !getenv("LBM_MARCH_KERNEL") && c->p.nx >= 64 && c->p.ny >= 32 &&
           (double)c->p.ny * c->slabs[0].pitch * 4.0 < 4.0e9) {
-        const int h = slab_wave_rows(c, c->p.ny);
-        if (371.0 * slab_wave_efficiency(c, c->p.ny, h) >= 300.0 * march_efficiency(c, march_pick_rows(c))) {
+        int h = 0;
+        const int cols_was = c->wave_cols;
+        if (wave_pick_cols(c, c->p.ny, &h) >= 300.0 * march_efficiency(c, march_pick_rows(c))) {
           c->time_block = 8; c->march_kernel = 1;
           if (c->wave_rows <= 0) c->wave_rows = h;
-        }
+        } else c->wave_cols = cols_was;
       }
     }
   }
@@ -1389,7 +1420,7 @@ int march_rows_for(const lbm_ctx* c, int ny_rows) {
 // work with it: a chunk costs 2K fill iterations, and waves that do not fill the last round leave slots idle.
 inline bool slab_is_wave(int K) { return K == 8 || K == 6; }
 // wave slots of the chip for lbm_wave<K> with the context's columns per lane
-int wave_slots(const lbm_ctx* c, int K = 8) { return std::max(c->ncu, 1) * std::max(wave_blocks_per_cu(K, wave_C(c, K)), 1) * (lbm::kWaveBlock / 64); }
+int wave_slots(const lbm_ctx* c, int K) { return std::max(c->ncu, 1) * std::max(wave_blocks_per_cu(K, wave_C(c, K)), 1) * (lbm::kWaveBlock / 64); }
 // The share of the chip's wave-slot time that is useful work with chunks of h rows: a chunk costs its 2K fill
 // iterations on top of its h, and the waves come in rounds of `slots`: up to three rounds a partial round costs a whole
 // one (4096^2: 118-row chunks = 0.98 rounds 285 GLUPS, 114-row chunks = 1.008 rounds 231; 5120^2: 91 rows = 1.99 rounds
@@ -1401,13 +1432,14 @@ double slab_wave_efficiency(const lbm_ctx* c, int ny_rows, int h, int K, int ext
   const long waves = (long)nwc * cdiv(ny_rows, h) + extra_waves, slots = wave_slots(c, K);
   const double r = (double)waves / slots;
   const double rounds = r <= 3.0 ? std::ceil(r) : r;
-  const double shape = rounds <= 1.0 ? 0.87 : 0.94;
+  // (two columns per lane: 0.91 - 0.96 measured for one round and for two alike)
+  const double shape = wave_C(c, K) == 2 ? 0.93 : rounds <= 1.0 ? 0.87 : 0.94;
   // (a level's fill rows are half empty on average: K of the 2K fill iterations' worth of work)
   return shape * (double)nwc * ny_rows / (rounds * slots * (h + 2.0 * K));
 }
 int slab_wave_rows(const lbm_ctx* c, int ny_rows, int K, int extra_waves) {
   if (c->wave_rows > 0) return std::min(c->wave_rows, ny_rows);
-  const int hmax = wave_C(c, K) == 2 ? 192 : 128;
+  const int hmax = wave_C(c, K) == 2 ? 320 : 128;
   int best_h = std::min(ny_rows, 128);
   double best = -1.0;
   for (int h = std::min(ny_rows, 32); h <= std::min(ny_rows, hmax); ++h) {        // (beyond 128 rows the one-column chunks get slower: measured)
@@ -1687,7 +1719,7 @@ void wave_plan(lbm_ctx* c) {
   if (bpc < 1) bpc = 4;
   c->wave_capacity = std::max(c->ncu, 1) * bpc * (lbm::kWaveBlock / 64);
   if (c->wave_rows > 0) return;
-  c->wave_rows = std::min(c->p.ny, K >= 8 ? 128 : K >= 6 ? 64 : 32);
+  c->wave_rows = (K == 8) ? slab_wave_rows(c, c->p.ny, 8) : std::min(c->p.ny, K >= 6 ? 64 : 32);   // (K = 8: whole rounds of the chip's wave slots)
 }
 
 // One lbm_wave launch: steps tt .. tt+K-1 of the lone slab, launch index li.

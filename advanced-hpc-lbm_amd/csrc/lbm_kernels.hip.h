@@ -186,6 +186,76 @@ __device__ __forceinline__ float collide_cell(float (&p)[9], bool is_blocked, fl
   return is_blocked ? 0.f : speed;
 }
 
+// The same collision for C cells of one lane at once, statement by statement across the cells: each cell sees exactly
+// collide_cell's sequence of float operations (the lattices stay bit-identical), but consecutive instructions belong to
+// DIFFERENT cells, so that a wave has C independent chains to issue from (lbm_wave with two columns per lane runs two
+// waves per SIMD: there it is instruction-level parallelism, not other waves, that has to keep the SIMD's issue slots full).
+template <bool FAST, int C>
+__device__ __forceinline__ void collide_cells(float (&p)[C][9], const bool (&is_blocked)[C], float omega, float (&speed)[C]) {
+#pragma clang fp contract(off)
+  const float w0 = 4.f / 9.f, w1 = 1.f / 9.f, w2 = 1.f / 36.f;
+  float rho[C], inv[C], ux[C], uy[C], usq[C], base[C], r0[C], r1[C], r2[C], upp[C], upm[C], d[C][9], t[C][9];
+#define LBM_EACH for (int c = 0; c < C; ++c)
+#pragma unroll
+  LBM_EACH rho[c] = p[c][0];
+#pragma unroll
+  for (int k = 1; k < 9; ++k) {
+#pragma unroll
+    LBM_EACH rho[c] += p[c][k];
+  }
+#pragma unroll
+  LBM_EACH inv[c] = recip<FAST>(rho[c]);
+#pragma unroll
+  LBM_EACH ux[c] = (p[c][1] + p[c][5] + p[c][8] - (p[c][3] + p[c][6] + p[c][7])) * inv[c];
+#pragma unroll
+  LBM_EACH uy[c] = (p[c][2] + p[c][5] + p[c][6] - (p[c][4] + p[c][7] + p[c][8])) * inv[c];
+#pragma unroll
+  LBM_EACH usq[c] = __builtin_fmaf(ux[c], ux[c], uy[c] * uy[c]);
+#pragma unroll
+  LBM_EACH base[c] = __builtin_fmaf(-1.5f, usq[c], 1.f);
+#pragma unroll
+  LBM_EACH { r0[c] = w0 * rho[c]; r1[c] = w1 * rho[c]; r2[c] = w2 * rho[c]; upp[c] = ux[c] + uy[c]; upm[c] = ux[c] - uy[c]; }
+#pragma unroll
+  LBM_EACH d[c][0] = r0[c] * base[c];
+#pragma unroll
+  LBM_EACH d[c][1] = r1[c] * __builtin_fmaf(ux[c], __builtin_fmaf(4.5f, ux[c], 3.f), base[c]);
+#pragma unroll
+  LBM_EACH d[c][2] = r1[c] * __builtin_fmaf(uy[c], __builtin_fmaf(4.5f, uy[c], 3.f), base[c]);
+#pragma unroll
+  LBM_EACH d[c][3] = r1[c] * __builtin_fmaf(-ux[c], __builtin_fmaf(-4.5f, ux[c], 3.f), base[c]);
+#pragma unroll
+  LBM_EACH d[c][4] = r1[c] * __builtin_fmaf(-uy[c], __builtin_fmaf(-4.5f, uy[c], 3.f), base[c]);
+#pragma unroll
+  LBM_EACH d[c][5] = r2[c] * __builtin_fmaf(upp[c], __builtin_fmaf(4.5f, upp[c], 3.f), base[c]);
+#pragma unroll
+  LBM_EACH d[c][6] = r2[c] * __builtin_fmaf(-upm[c], __builtin_fmaf(-4.5f, upm[c], 3.f), base[c]);
+#pragma unroll
+  LBM_EACH d[c][7] = r2[c] * __builtin_fmaf(-upp[c], __builtin_fmaf(-4.5f, upp[c], 3.f), base[c]);
+#pragma unroll
+  LBM_EACH d[c][8] = r2[c] * __builtin_fmaf(upm[c], __builtin_fmaf(4.5f, upm[c], 3.f), base[c]);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    LBM_EACH t[c][k] = __builtin_fmaf(omega, d[c][k] - p[c][k], p[c][k]);
+  }
+#pragma unroll
+  LBM_EACH speed[c] = is_blocked[c] ? 0.f : root<FAST>(usq[c]);
+#pragma unroll
+  LBM_EACH {
+    const float b1 = p[c][3], b2 = p[c][4], b3 = p[c][1], b4 = p[c][2], b5 = p[c][7], b6 = p[c][8], b7 = p[c][5], b8 = p[c][6];
+    p[c][0] = is_blocked[c] ? p[c][0] : t[c][0];
+    p[c][1] = is_blocked[c] ? b1 : t[c][1];
+    p[c][2] = is_blocked[c] ? b2 : t[c][2];
+    p[c][3] = is_blocked[c] ? b3 : t[c][3];
+    p[c][4] = is_blocked[c] ? b4 : t[c][4];
+    p[c][5] = is_blocked[c] ? b5 : t[c][5];
+    p[c][6] = is_blocked[c] ? b6 : t[c][6];
+    p[c][7] = is_blocked[c] ? b7 : t[c][7];
+    p[c][8] = is_blocked[c] ? b8 : t[c][8];
+  }
+#undef LBM_EACH
+}
+
 // The accelerate phase for one cell of row ny-2 (d2q9-bgk.c:246-258).
 __device__ __forceinline__ void accelerate_cell(float (&p)[9], bool is_blocked, float a1, float a2) {
 #pragma clang fp contract(off)

@@ -244,12 +244,24 @@ void lbm_wave(const WaveArgs a) {
             p[c][7] = (c == C - 1) ? from_east(cur[ce][7]) : cur[ce][7];
             p[c][8] = (c == 0) ? from_west(cur[cw][8]) : cur[cw][8];
           }
-#pragma unroll
-          for (int c = 0; c < C; ++c) {
-            const bool blk = ((mreg[c] >> l) & 1u) != 0u;
-            const float sp = collide_cell<FAST>(p[c], blk, a.omega);
-            if (acc) accelerate_cell(p[c], blk, a.a1, a.a2);
+          if constexpr (C == 1) {
+            const bool blk = ((mreg[0] >> l) & 1u) != 0u;
+            const float sp = collide_cell<FAST>(p[0], blk, a.omega);
+            if (acc) accelerate_cell(p[0], blk, a.a1, a.a2);
             sum[l - 1] += (out_ok && own_row) ? sp : 0.f;
+          } else {
+            bool blk[C];
+            float sp[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) blk[c] = ((mreg[c] >> l) & 1u) != 0u;
+            collide_cells<FAST, C>(p, blk, a.omega, sp);      // the lane's cells statement by statement: independent chains
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+              if (acc) accelerate_cell(p[c], blk[c], a.a1, a.a2);
+            // (the K sums stay in registers: as lane-private LDS words -- read, add, write per level -- they cost the two-column
+            // kernel 12 % at K = 8 and 18 % at K = 6, more than the eight dwords the K = 8 loop spills without them)
+#pragma unroll
+            for (int c = 0; c < C; ++c) sum[l - 1] += (out_ok && own_row) ? sp[c] : 0.f;
           }
         }
         if (l >= 2 && (STEADY || j >= 2 * (l - 1))) {   // the producer's row of this iteration becomes history for the next two

@@ -881,14 +881,16 @@ def test_marching_kernel_is_the_default_on_big_lattices_only(gpu):
         p = L.Param(n, n, 10, 10, 0.1, 0.01, 1.85)
         with L.Lattice(p, np.zeros((n, n), dtype=np.int32)) as lat:
             assert lat.info("time_block_active") == want, n
-            assert lat.info("march_kernel") == 0                   # lbm_march wherever it can run
-    # from ~5000^2 up: eight steps per pass in registers (lbm_wave<8>), chunk height such that the waves come in whole
-    # rounds of the chip's wave slots (5120^2: 107 wave columns x 57 chunks of 90 rows = 6099 waves for 2 x 3072 slots)
-    for n, rows_ok in ((5120, (90, 91)), (8192, (128,))):
+            assert lat.info("march_kernel") == 0                   # lbm_march where it fills the chip and lbm_wave does not beat it
+    # from 4096^2 up: eight steps per pass in registers (lbm_wave<8>), two columns per lane, chunk height such that the waves
+    # come in whole rounds of the chip's wave slots (2048 at two waves per SIMD: 4096^2 37 wave columns x 55 chunks of 75 rows
+    # = 2035 waves; 8192^2 74 x 27 chunks of 304 rows = 1998)
+    for n, rows_ok in ((4096, (75, 76)), (8192, (304, 305, 149))):
         p = L.Param(n, n, 10, 10, 0.1, 0.01, 1.85)
         with L.Lattice(p, np.zeros((n, n), dtype=np.int32)) as lat:
-            assert lat.info("time_block_active") == 8 and lat.info("march_kernel") == 1, n
-            if lat.info("compute_units") == 256 and lat.info("wave_capacity") in (0, 3072):
+            assert lat.info("time_block_active") == 8 and lat.info("march_kernel") == 1 and lat.info("wave_cols_active") == 2, n
+            lat.run(8)
+            if lat.info("compute_units") == 256 and lat.info("wave_capacity") == 2048:
                 assert int(lat.info("wave_rows")) in rows_ok, (n, lat.info("wave_rows"))
     # a width lbm_march cannot take (not a multiple of 4): lbm_wave<6> on a big lattice
     p = L.Param(2050, 2048, 10, 10, 0.1, 0.01, 1.85)
@@ -1432,3 +1434,57 @@ def test_register_tile_asynchronous_loop_equals_single_step_kernel(gpu, tile, nx
         st_b = b.read_state()
     assert np.array_equal(st_a.view(np.uint32), st_b.view(np.uint32))
     assert np.allclose(av_a, av_b, rtol=2e-6, atol=0)
+
+
+# (nx, ny, slabs on one GPU, transport) -> (engine the next run tries first: 3 = lbm_regtile, 1 = streaming kernels;
+#  steps per pass; 1 = lbm_wave rather than lbm_march; columns per lane of lbm_wave).  Written by tools/selection_table.py on an
+# MI355X (256 CUs); "rccl" = one rank of a RCCL job as a ring of one.
+KERNEL_SELECTION = {
+    (128, 128, 1, "none"): (3, 2, 0, 0),
+    (128, 256, 1, "none"): (3, 2, 0, 0),
+    (256, 256, 1, "none"): (3, 2, 0, 0),
+    (1024, 1024, 1, "none"): (3, 2, 0, 0),
+    (100, 100, 1, "none"): (1, 2, 0, 0),
+    (1000, 600, 1, "none"): (1, 2, 0, 0),
+    (2048, 2048, 1, "none"): (1, 4, 0, 0),
+    (2050, 2048, 1, "none"): (1, 6, 1, 1),
+    (4096, 4096, 1, "none"): (1, 8, 1, 2),
+    (5120, 5120, 1, "none"): (1, 8, 1, 2),
+    (8192, 8192, 1, "none"): (1, 8, 1, 2),
+    (8192, 1024, 1, "none"): (1, 8, 1, 2),
+    (48, 4096, 1, "none"): (1, 1, 0, 0),
+    (64, 8, 1, "none"): (3, 1, 0, 0),
+    (1024, 128, 1, "none"): (3, 2, 0, 0),
+    (1024, 1024, 2, "copy"): (1, 2, 0, 0),
+    (1024, 1024, 8, "copy"): (1, 2, 0, 0),
+    (1024, 1024, 8, "p2p"): (1, 2, 0, 0),
+    (8192, 8192, 2, "p2p"): (1, 8, 1, 2),
+    (8192, 8192, 4, "p2p"): (1, 8, 1, 2),
+    (8192, 8192, 8, "p2p"): (1, 8, 1, 2),
+    (8192, 8192, 8, "copy"): (1, 8, 1, 2),
+    (4096, 4096, 4, "p2p"): (1, 8, 1, 1),
+    (2048, 2048, 2, "copy"): (1, 4, 0, 0),
+    (1000, 600, 3, "copy"): (1, 1, 0, 0),
+    (256, 256, 4, "p2p"): (1, 2, 0, 0),
+    (6144, 6144, 1, "none"): (1, 8, 1, 2),
+    (4096, 4096, 2, "p2p"): (1, 8, 1, 2),
+    (8192, 1024, 1, "rccl"): (1, 8, 1, 1),
+    (8192, 2048, 1, "rccl"): (1, 8, 1, 1),
+    (1024, 128, 1, "rccl"): (1, 2, 0, 0),
+}
+
+
+def test_kernel_selection_table(gpu):
+    """the engine / kernel selection heuristics (lbm_api.hip: finish_create, plan_regtile, wave_pick_cols,
+    march_eligible, p2p_march_on, march_bands_on) over 31 (lattice, slab count, transport) points: which engine a run tries
+    first, how many steps a pass fuses, which marching kernel, how many columns per lane.  No lattice is advanced."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import selection_table
+    L = gpu
+    with L.Lattice(L.Param(64, 64, 1, 1, 0.1, 0.01, 1.85), np.zeros((64, 64), dtype=np.int32)) as lat:
+        if lat.info("compute_units") != 256:
+            pytest.skip("the table is for 256 CUs")
+    assert set(selection_table.POINTS) == set(KERNEL_SELECTION)
+    wrong = {pt: (selection_table.probe(*pt), want) for pt, want in KERNEL_SELECTION.items() if selection_table.probe(*pt) != want}
+    assert not wrong, wrong
