@@ -198,7 +198,7 @@ struct lbm_ctx {
                                // register pipeline, K = 4 / 6 / 8, any width from 64 up), -1 = lbm_march where it can run
                                // (269 GLUPS at 8192^2 against 262 for lbm_wave<8>), lbm_wave elsewhere
   int wave_rows = 0;           // rows per chunk of lbm_wave; 0 = not chosen yet
-  int wave_cols = 1;           // columns per lane of lbm_wave: 1 (a wave delivers 64 - 2K columns) or 2 (128 - 2K; K = 6, 8; even widths from 128)
+  int wave_cols = 1;           // columns per lane of lbm_wave: 1 (a wave delivers 64 - 2K columns) or 2 (128 - 2K; K = 8; even widths from 128)
   int wave_capacity = 0;       // waves of lbm_wave<time_block> the device holds at once (occupancy query)
   uint32_t seq = 0;            // peer-to-peer: sequence number of the last launch group (same on all slabs)
   bool p2p_connected = false;
@@ -500,9 +500,9 @@ bool t2_eligible(const lbm_ctx* c) {
 
 // Steps per pass of the marching kernel (lbm_march.hip.h).
 constexpr int kMarchK = 4;
-// lbm_wave: columns per lane actually used (two need an even width of at least one 128-column strip and K = 6 or 8),
+// lbm_wave: columns per lane actually used (two need an even width of at least one 128-column strip and K = 8),
 // and the columns a wave delivers
-inline int wave_C(const lbm_ctx* c, int K) { return (c->wave_cols == 2 && (K == 6 || K == 8) && c->p.nx % 2 == 0 && c->p.nx >= 128) ? 2 : 1; }
+inline int wave_C(const lbm_ctx* c, int K) { return (c->wave_cols == 2 && K == 8 && c->p.nx % 2 == 0 && c->p.nx >= 128) ? 2 : 1; }
 inline int wave_out_cols(const lbm_ctx* c, int K) { return 64 * wave_C(c, K) - 2 * K; }
 
 // The marching kernel runs on a lattice alone on its GPU (periodic wrap inside the kernel); its row
@@ -1376,7 +1376,7 @@ bool march_slabs_setup(lbm_ctx* c) {
   if (c->march_slabs >= 0) return c->march_slabs == 1;
   c->march_slabs = 0;
   if (c->rank_mode || c->exchange == 0 || c->exchange == LBM_EXCHANGE_RCCL) return false;
-  const int K = (c->time_block == 8 || c->time_block == 6) ? c->time_block : kMarchK;
+  const int K = (c->time_block == 8) ? 8 : kMarchK;
   if (K != kMarchK ? c->p.nx < 64 : (c->p.nx % 4 != 0 || c->p.nx < lbm::MarchCfg<kMarchK>::W)) return false;
   const int ns = (int)c->slabs.size();
   for (auto& s : c->slabs)
@@ -1395,10 +1395,10 @@ bool march_slabs_setup(lbm_ctx* c) {
   c->march_slabs = 1;
   return true;
 }
-// Steps per marching pass of a context whose slabs trade rows: 8 / 6 = lbm_wave<8> / <6>, 4 = lbm_march, 0 = no marching.
+// Steps per marching pass of a context whose slabs trade rows: 8 = lbm_wave<8>, 4 = lbm_march, 0 = no marching.
 inline int slab_K(const lbm_ctx* c) {
   if (c->exchange == 0 || (c->variant & 8)) return 0;
-  if (c->time_block == 8 || c->time_block == 6) return (c->p.nx >= 64) ? c->time_block : 0;
+  if (c->time_block == 8) return (c->p.nx >= 64) ? 8 : 0;
   if (c->time_block == kMarchK) return (c->p.nx % 4 == 0 && c->p.nx >= lbm::MarchCfg<kMarchK>::W) ? kMarchK : 0;
   return 0;
 }
@@ -1418,7 +1418,7 @@ int march_rows_for(const lbm_ctx* c, int ny_rows) {
 }
 // Rows per chunk of lbm_wave<8> on a slab of ny_rows rows, and the share of the chip's wave-slot time that is useful
 // work with it: a chunk costs 2K fill iterations, and waves that do not fill the last round leave slots idle.
-inline bool slab_is_wave(int K) { return K == 8 || K == 6; }
+inline bool slab_is_wave(int K) { return K == 8; }
 // wave slots of the chip for lbm_wave<K> with the context's columns per lane
 int wave_slots(const lbm_ctx* c, int K) { return std::max(c->ncu, 1) * std::max(wave_blocks_per_cu(K, wave_C(c, K)), 1) * (lbm::kWaveBlock / 64); }
 // The share of the chip's wave-slot time that is useful work with chunks of h rows: a chunk costs its 2K fill
@@ -1679,8 +1679,8 @@ int launch_band_group(lbm_ctx* c, int li, int tt, bool accel_out, bool fold_prev
 }
 
 // ---- lbm_wave: K steps per pass, one wave per strip of 64 (or 128) columns
-// The instantiations: a lattice alone (K = 4, 6, 8; one column per lane, or two at K = 6, 8) and a slab with neighbours
-// (K = 6, 8); flavour = IEEE or fast rcp / sqrt (bit 0) x nontemporal stores (bit 1).
+// The instantiations: a lattice alone (K = 4, 6, 8 with one column per lane, K = 8 with two) and a slab with neighbours
+// (K = 8, one or two columns); flavour = IEEE or fast rcp / sqrt (bit 0) x nontemporal stores (bit 1).
 template <int K, bool SLAB, int C>
 wave_fn wave_kernel_f(int flavour) {
   switch (flavour & 3) {
@@ -1691,12 +1691,9 @@ wave_fn wave_kernel_f(int flavour) {
   }
 }
 wave_fn wave_kernel(int K, bool slab, int C, int flavour) {
-  if (slab) {
-    if (K == 8) return C == 2 ? wave_kernel_f<8, true, 2>(flavour) : wave_kernel_f<8, true, 1>(flavour);
-    return C == 2 ? wave_kernel_f<6, true, 2>(flavour) : wave_kernel_f<6, true, 1>(flavour);
-  }
+  if (slab) return C == 2 ? wave_kernel_f<8, true, 2>(flavour) : wave_kernel_f<8, true, 1>(flavour);     // (K = 8 only)
   if (K == 8) return C == 2 ? wave_kernel_f<8, false, 2>(flavour) : wave_kernel_f<8, false, 1>(flavour);
-  if (K == 6) return C == 2 ? wave_kernel_f<6, false, 2>(flavour) : wave_kernel_f<6, false, 1>(flavour);
+  if (K == 6) return wave_kernel_f<6, false, 1>(flavour);
   return wave_kernel_f<4, false, 1>(flavour);
 }
 

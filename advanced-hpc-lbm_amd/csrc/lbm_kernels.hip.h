@@ -72,6 +72,22 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// The same sum by DPP adds alone (no LDS permutes, no lgkmcnt waits): row_shr 1, 2, 4, 8 gather every row of 16 lanes in
+// its lane 15, row_bcast:15 / row_bcast:31 carry the row sums on; the total is in LANE 63 and returned wave-uniformly.
+// A chain of six dependent v_add_f32 against six ds_bpermute round trips (~700 cycles): for sums taken inside a loop.
+// (The order of the additions differs from wave_sum's: results agree to rounding, not bit for bit.)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define LBM_DPP_ADD(ctrl, rmask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, true))
+  LBM_DPP_ADD(0x111, 0xf);   // row_shr:1
+  LBM_DPP_ADD(0x112, 0xf);   // row_shr:2
+  LBM_DPP_ADD(0x114, 0xf);   // row_shr:4
+  LBM_DPP_ADD(0x118, 0xf);   // row_shr:8   -> lane 15 of every row: the row's sum
+  LBM_DPP_ADD(0x142, 0xa);   // row_bcast:15, rows 1 and 3 -> lane 31: rows 0+1, lane 63: rows 2+3
+  LBM_DPP_ADD(0x143, 0xc);   // row_bcast:31, rows 2 and 3 -> lane 63: everything
+#undef LBM_DPP_ADD
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // Block-wide sum; result valid in thread 0.  `red` holds one slot per wave (NW waves per block).
 template <typename T, int NW = kBlock / 64>
 __device__ __forceinline__ T block_sum(T v, T* red) {

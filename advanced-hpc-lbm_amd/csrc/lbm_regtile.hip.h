@@ -441,9 +441,9 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave's edge rows of state s-1 are in LDS
         if (*lds_abort != 0u) { aborted = true; break; }
         stamp(s, 0);
-        if (s > 1 && tid < 64) {                       // speed sum of step s-1
-          float v = (lane < nw) ? red[par * 16 + lane] : 0.f;
-          v = wave_sum(v);
+        if (s > 1 && tid < 64) {                       // speed sum of step s-1 (DPP adds: the LDS-permute form cost wave 0 ~1300 cycles at
+          float v = (lane < nw) ? red[par * 16 + lane] : 0.f;    // the head of EVERY step, and the tile's barrier waits for its slowest wave)
+          v = wave_sum_dpp(v);
           if (tid == 0) a.partials[(long)(s - 2) * nt + tile] = v;
         }
         const bool laststep = (s == a.nsteps), firststep = (s == 1);
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
         if constexpr (R > 2) { one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{}); }
         if (!laststep) publish_lds(s & 1);
         stamp(s, 13);
-        sp = wave_sum(sp);
+        sp = wave_sum_dpp(sp);
         if (lane == 0) red[(s & 1) * 16 + w] = sp;
       }
       // nothing of the loop's mail is in flight beyond this point (the slots' last fetches are never used: retire them)
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
     stamp(s, 0);
     if (s > 1 && tid < 64) {                       // speed sum of step s-1
       float v = (lane < nw) ? red[par * 16 + lane] : 0.f;   // (written with parity (s-1)&1 at the end of step s-1)
-      v = wave_sum(v);
+      v = wave_sum_dpp(v);
       if (tid == 0) a.partials[(long)(s - 2) * nt + tile] = v;
     }
     const bool laststep = (s == a.nsteps);
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
     if (!down) sweep(std::true_type{}); else sweep(std::false_type{});
     if (!laststep) publish_lds(s & 1);
     stamp(s, 13);
-    sp = wave_sum(sp);
+    sp = wave_sum_dpp(sp);
     if (lane == 0) red[(s & 1) * 16 + w] = sp;
   }
   __syncthreads();

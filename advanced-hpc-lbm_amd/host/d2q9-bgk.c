@@ -231,8 +231,12 @@ int main(int argc, char* argv[])
       printf("Steps per pass:				%d\n", params.maxIters);
       printf("HBM bytes per update (lattice in + out / steps):	%.4f\n", bytes);
     } else {
-      const double bytes = tb >= 4.0 ? (wave > 0.5 ? (36.0 * 64.0 / (64.0 - 2.0 * tb) + 36.0) / tb : 19.37) : tb >= 2.0 ? 38.88 : 72.0;
-      printf("Kernel:					%s\n", tb >= 4.0 ? (wave > 0.5 ? "lbm_wave" : "lbm_march") : tb >= 2.0 ? "lbm_sweep2" : "lbm_sweep");
+      double cols = 1.0;
+      lbm_get_info(ctx, "wave_cols_active", &cols);
+      const double wcols = 64.0 * (cols > 1.5 ? 2.0 : 1.0);     /* columns a wave covers; it delivers wcols - 2K of them */
+      const double bytes = tb >= 4.0 ? (wave > 0.5 ? (36.0 * wcols / (wcols - 2.0 * tb) + 36.0) / tb : 19.37) : tb >= 2.0 ? 38.88 : 72.0;
+      printf("Kernel:					%s\n", tb >= 4.0 ? (wave > 0.5 ? (cols > 1.5 ? "lbm_wave, two columns per lane" : "lbm_wave") : "lbm_march")
+                                                  : tb >= 2.0 ? "lbm_sweep2" : "lbm_sweep");
       printf("Steps per pass:				%d\n", (int)tb);
       printf("HBM GB/s at %.1f B per update:		%.1f\n", bytes, mlups * bytes / 1000.0);
       printf("Fraction of HBM peak (8 TB/s x GPUs):	%.4f\n", mlups * bytes / 1000.0 / (8000.0 * ngpus));

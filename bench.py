@@ -185,13 +185,16 @@ def kernel_of(lat, tb):
       lbm_sweep2   two steps per pass, 64x16 tiles + ring  (36 x 66x18/(64x16) + 36) / 2 = 38.9
       lbm_march    four steps per pass, 224 of 256 columns (36 x 258/224 + 36) / 4       = 19.4
       lbm_wave<K>  K steps per pass, 64-2K of 64 columns   (36 x 64/(64-2K) + 36) / K    = 19.3 / 13.7 / 10.5 (K = 4 / 6 / 8)
+      lbm_wave<8>x2  two columns per lane, 112 of 128      (36 x 128/112 + 36) / 8       = 9.64
       lbm_regtile  the whole run on chip (registers): one load and one store of the lattice per RUN; the figure
                    reported is that, per step -- the kernel is bound by arithmetic and by the hand-off between
                    neighbouring tiles, not by HBM"""
     if int(lat.info("engine_last")) == 3:
         return "lbm_regtile", None
-    if tb >= 4 and int(lat.info("march_kernel")) == 1:       # one wave per 64 columns, 64 - 2K delivered
-        return f"lbm_wave<{tb}>", (36.0 * 64 / (64 - 2 * tb) + 36.0) / tb
+    if tb >= 4 and int(lat.info("march_kernel")) == 1:       # one wave per 64 (128) columns, 64 - 2K (128 - 2K) delivered
+        cols = int(lat.info("wave_cols_active"))
+        w = 64 * cols
+        return f"lbm_wave<{tb}>" + ("x2" if cols == 2 else ""), (36.0 * w / (w - 2 * tb) + 36.0) / tb
     if tb == 4:
         return "lbm_march<4>", (36.0 * 258 / 224 + 36.0) / 4
     if tb == 2:

@@ -1099,7 +1099,7 @@ def test_register_tile_kernel_that_cannot_finish_falls_back_to_the_streaming_ker
 # Round 3: the kernels that used to be checked only against lbm_sweep, now against the ORACLE and the golden files
 # directly ("parity evidence"), and the advisor's regressions.
 
-@pytest.mark.parametrize("K", [6, 8])
+@pytest.mark.parametrize("K", [8])
 @pytest.mark.parametrize("nx,ny,rows,steps", [
     (128, 40, 0, [1, 0]), (130, 30, 7, [2, 1]), (250, 77, 16, [3, 1]),        # one wave column of 128; widths that are no multiple of 4
     (480, 70, 0, [3, 2]), (1000, 24, 8, [2, 3]), (1024, 1024, 0, [4, 3]), (1024, 1024, 149, [2, 5]),
@@ -1135,6 +1135,8 @@ def test_wave_kernels_against_float_oracle(gpu, O, oracle, deck, K, cols):
     equilibrium of a shipped deck (128x256: rows 0 / 255 open, the y-wrap is live; 1024x1024: the headline deck):
     50 = six / eight groups of K plus a remainder through lbm_sweep2.  Same bars as the one-step kernel's test."""
     L = gpu
+    if K == 6 and cols == 2:
+        pytest.skip("two columns per lane: K = 8 only")
     pf, of = deck_paths(deck)
     p = L.read_params(pf)
     ob = L.read_obstacles(of, p)
@@ -1356,7 +1358,7 @@ def test_reference_form_of_the_speed_sum_is_selectable(gpu, O, oracle, deck):
 
 
 @pytest.mark.parametrize("K,cols,nx,ny,steps", [
-    (8, 1, 256, 64, [8]), (8, 1, 100, 96, [16, 11]), (8, 2, 480, 200, [29]), (6, 2, 1024, 256, [12, 7]), (6, 1, 512, 96, [18, 1]),
+    (8, 1, 256, 64, [8]), (8, 1, 100, 96, [16, 11]), (8, 2, 480, 200, [29]), (8, 2, 1024, 256, [16, 7]), (8, 1, 512, 96, [24, 1]),
     (8, 1, 2048, 2048, [19]), (8, 2, 2048, 2048, [16, 3]),      # >= 4 M cells: edge launches on their own stream
 ])
 def test_marching_kernel_with_ghost_bands_over_rccl(gpu, K, cols, nx, ny, steps):
