@@ -175,6 +175,17 @@ struct Slab {
   int nb_nyl[2] = {0, 0};
   void* nb_ipc[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // hipIpc mappings to close (rank mode)
   uint32_t cnt_s_total = 0, cnt_n_total = 0;
+  // register tiles across slabs (lbm_regtile_slabs): this slab's mailboxes (uncached: the neighbours may store into them
+  // over xGMI), its per-step tile sums, and the neighbours' mail areas as this device sees them ([0] south, [1] north)
+  char* tmail = nullptr;
+  size_t tmail_bytes = 0;
+  float* rpartials = nullptr;
+  long rpartials_cap = 0;          // in steps
+  char* tmail_nb[2] = {nullptr, nullptr};
+  size_t tmail_nb_bytes[2] = {0, 0};
+  bool tmail_nb_ipc[2] = {false, false};
+  uint32_t* rabort = nullptr;      // abort word of this slab's device group (owned by the group's first slab)
+  hipEvent_t ev_rt = nullptr;      // "the group's launch is over" (recorded on the first slab's stream)
 };
 
 }  // namespace
@@ -226,6 +237,10 @@ struct lbm_ctx {
   bool resident_broken = false;   // the resident kernel cannot run here (not every tile resident, set-up failed, or a run
                                   // gave up): stay with the streaming kernels
   char resident_why[160] = "";    // ... and why (lbm_last_error does not carry it: the run itself succeeds)
+  // register tiles across slabs: the same 64 x ty tiling on every slab (ty == 0: none); nty = tile rows per slab
+  struct { int ty = 0, r = 0, nw = 0, ntx = 0, nty = 0, bpc = 0; } splan;
+  lbm::RegTileArgs* rtable = nullptr;   // pinned, device-mapped: one entry per local slab, grouped by device
+  lbm::RegTileArgs* rtable_dev = nullptr;
   int ncu = 0;                 // CUs of slab 0's device
   double gpu_ms = 0.0, wall_ms = 0.0;
 };
@@ -735,6 +750,10 @@ int ensure_sums(Slab& s, int nsteps) {
 }
 
 bool plan_regtile(lbm_ctx* c);    // resident engine, below
+bool plan_regtile_slabs(lbm_ctx* c);
+struct Slab;
+int regtile_slab_mail_alloc(lbm_ctx* c, Slab& s);
+size_t regtile_slab_mail_bytes(const lbm_ctx* c);
 typedef void (*wave_fn)(const lbm::WaveArgs);
 wave_fn wave_kernel(int K, bool slab, int C, int flavour);   // the lbm_wave instantiations, below
 bool march_slabs_setup(lbm_ctx* c);   // marching kernel across slabs, below
@@ -796,6 +815,17 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
     if (e) c->engine = (atoi(e) == 0 || atoi(e) == 1 || atoi(e) == 3) ? atoi(e) : 0;
     if ((e = getenv("LBM_REGTILE_ASYNC"))) c->regtile_async = atoi(e) ? 1 : 0;
     if (!exchanging && c->slabs.size() == 1) plan_regtile(c);
+    if (exchanging && plan_regtile_slabs(c) && c->rank_mode && c->nranks > 1) {
+      // one process per GPU: the neighbours find this slab's mail area through a hipIpc handle in its halo block
+      Slab& s0 = c->slabs[0];
+      int rc = regtile_slab_mail_alloc(c, s0);
+      if (rc) { (void)hipGetLastError(); c->splan.ty = 0; }
+      else {
+        hipIpcMemHandle_t h;
+        if (hipIpcGetMemHandle(&h, s0.tmail) != hipSuccess) { (void)hipGetLastError(); c->splan.ty = 0; }
+        else HIPC(hipMemcpy(s0.comm_block + 4 * s0.halo_bytes + 512 + 192, &h, sizeof(h), hipMemcpyHostToDevice));
+      }
+    }
     // Four steps per pass (lbm_march) where its strips and chunks fill the chip: measured 1.5-1.6x
     // lbm_sweep2 from 2048^2 up (194 / 226 / 238 GLUPS at 2048^2 / 4096^2 / 8192^2 against 129 / 146 /
     // 150), 0.8x at 1024^2, where 5 strips x 32-row chunks leave the CUs 49 % busy by the estimate
@@ -963,6 +993,19 @@ int p2p_connect_ipc(lbm_ctx* c, const char* handles, int nranks) {
       }
       s.nb_lat[side][0] = (const float*)s.nb_ipc[side][0]; s.nb_lat[side][1] = (const float*)s.nb_ipc[side][1];
       s.nb_blocked[side] = (const uint8_t*)s.nb_ipc[side][2];
+    }
+    // the neighbour's mail area (register tiles across slabs): a fourth handle behind the three, zero if it has none
+    if (c->splan.ty > 0 && r != c->rank) {
+      if (side == 1 && north == south) { s.tmail_nb[1] = s.tmail_nb[0]; s.tmail_nb_bytes[1] = s.tmail_nb_bytes[0]; s.tmail_nb_ipc[1] = false; }
+      else {
+        hipIpcMemHandle_t h, zero;
+        memset(&zero, 0, sizeof(zero));
+        HIPC(hipMemcpy(&h, blocks[side] + 4 * s.halo_bytes + 512 + 192, sizeof(h), hipMemcpyDeviceToHost));
+        void* ptr = nullptr;
+        if (memcmp(&h, &zero, sizeof(h)) != 0 && hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess) == hipSuccess) {
+          s.tmail_nb[side] = (char*)ptr; s.tmail_nb_bytes[side] = regtile_slab_mail_bytes(c); s.tmail_nb_ipc[side] = true;
+        } else { (void)hipGetLastError(); c->splan.ty = 0; }      // (no mail area over there, or not mappable: the streaming kernels)
+      }
     }
   }
   c->p2p_connected = true;
@@ -1786,14 +1829,15 @@ namespace {
 // End of a run: reduce across ranks (if there is a communicator), fetch the per-step sums and the
 // peer-to-peer error word through pinned staging with async copies queued behind the step loop,
 // then ONE wait per slab (s.sc has joined the edge and exchange streams by then).
-int collect_sums(lbm_ctx* c, int nsteps, float* av_vels, std::chrono::steady_clock::time_point wall0) {
+int collect_sums(lbm_ctx* c, int nsteps, float* av_vels, std::chrono::steady_clock::time_point wall0, int extra = 0) {
+  // (extra: doubles behind the per-step sums that are reduced and fetched with them -- run_regtile_slabs' "somebody gave up")
   if (c->rank_mode && c->slabs[0].comm != nullptr) {   // (a ring of one rank has a communicator too: identity)
     Slab& s = c->slabs[0];
-    NCCLC(rccl::AllReduce(s.sums, s.sums, (size_t)nsteps, rccl::kFloat64, rccl::kSum, s.comm, s.sc));
+    NCCLC(rccl::AllReduce(s.sums, s.sums, (size_t)(nsteps + extra), rccl::kFloat64, rccl::kSum, s.comm, s.sc));
   }
   for (auto& s : c->slabs) {
     HIPC(hipSetDevice(s.dev));
-    if (av_vels && !s.sums_direct) HIPC(hipMemcpyAsync(s.sums_host, s.sums, sizeof(double) * nsteps, hipMemcpyDeviceToHost, s.sc));
+    if ((av_vels || extra) && !s.sums_direct) HIPC(hipMemcpyAsync(s.sums_host, s.sums, sizeof(double) * (nsteps + extra), hipMemcpyDeviceToHost, s.sc));
     if (s.counters) HIPC(hipMemcpyAsync(s.err_host, s.counters + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, s.sc));
   }
   double gpu_ms = 0.0;
@@ -1900,8 +1944,8 @@ regtile_fn regtile_kernel(int r, bool fast, int dbg, bool trace, bool async) {
 // without asking) and ASK the runtime how many of its blocks a CU takes.  The tiles wait on each other, so all of them must
 // be resident at once: blocks per CU x CUs >= tiles, or the launch would stall until its waits time out.  Returns the
 // blocks per CU, or -1 with the reason in lbm_last_error.
-int regtile_prepare(const lbm_ctx* c, regtile_fn fn, int dev, int threads, unsigned shm) {
-  struct Seen { regtile_fn fn; int dev; };
+int regtile_prepare(const lbm_ctx* c, const void* fn, int dev, int threads, unsigned shm) {
+  struct Seen { const void* fn; int dev; };
   static std::mutex mu;
   static std::vector<Seen> raised;
   {
@@ -1909,7 +1953,7 @@ int regtile_prepare(const lbm_ctx* c, regtile_fn fn, int dev, int threads, unsig
     bool have = false;
     for (auto& e : raised) have = have || (e.fn == fn && e.dev == dev);
     if (!have) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) {
         (void)hipGetLastError();
         if (shm > 64u * 1024u) { fail(LBM_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e)); return -1; }
@@ -1917,7 +1961,7 @@ int regtile_prepare(const lbm_ctx* c, regtile_fn fn, int dev, int threads, unsig
     }
   }
   int n = 0;
-  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(fn), threads, shm);
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, threads, shm);
   if (e != hipSuccess) { (void)hipGetLastError(); fail(LBM_EHIP, "occupancy query failed: %s", hipGetErrorString(e)); return -1; }
   (void)c;
   return n;
@@ -1937,7 +1981,7 @@ int run_regtile(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
   static const bool want_stats = getenv("LBM_REGTILE_STATS") != nullptr;   // development: missed polls per run, and a trace
   const regtile_fn fn = regtile_kernel(t.r, fast, dbg ? atoi(dbg) : 0, want_stats && getenv("LBM_REGTILE_TRACE"), c->regtile_async != 0);
   if (c->tplan.bpc == 0) {                             // first run of this tiling: is every tile resident at once?
-    const int n = regtile_prepare(c, fn, s.dev, (int)block.x, shm);
+    const int n = regtile_prepare(c, reinterpret_cast<const void*>(fn), s.dev, (int)block.x, shm);
     c->tplan.bpc = (n < 0) ? -1 : n;
     if (n < 0) snprintf(c->resident_why, sizeof(c->resident_why), "%s", lbm_last_error());
     else if ((long)n * std::max(c->ncu, 1) < (long)ntiles) {
@@ -1947,7 +1991,16 @@ int run_regtile(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
   }
   if (c->tplan.bpc < 0) return fail(LBM_EINVAL, "register tiling not usable: %s", c->resident_why);
   if (!c->tmail) {
-    HIPC(hipMalloc((void**)&c->tmail, mail_bytes));
+    // Uncached device memory where the device offers it: the granules are written once and read once, by another CU, and
+    // every access is sc1 anyway -- without the L2 allocation a hand-off is shorter (1024x1024: 4.14 -> 3.48 us per step, found
+    // when the slabs' mail areas, uncached for the sake of stores from other GPUs, ran faster than this one;
+    // LBM_REGTILE_MAIL_CACHED=1: ordinary device memory)
+    static const bool cached = getenv("LBM_REGTILE_MAIL_CACHED") && atoi(getenv("LBM_REGTILE_MAIL_CACHED"));
+    if (cached || hipExtMallocWithFlags((void**)&c->tmail, mail_bytes, hipDeviceMallocUncached) != hipSuccess) {
+      (void)hipGetLastError();
+      c->tmail = nullptr;
+      HIPC(hipMalloc((void**)&c->tmail, mail_bytes));
+    }
     HIPC(hipMemsetAsync(c->tmail, 0, mail_bytes, s.sc));
     if (!c->rabort) {
       HIPC(hipMalloc((void**)&c->rabort, 64));
@@ -2036,6 +2089,272 @@ int run_regtile(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
     HIPC(hipMemsetAsync(c->rabort, 0, 64, s.sc));
     HIPC(hipStreamSynchronize(s.sc));
     resident_give_up(c, "a tile waited 1 s for a neighbour: not every tile was running at once");
+    return LBM_OK;
+  }
+  c->cur ^= 1;
+  *done = true;
+  return LBM_OK;
+}
+
+// ---- register tiles ACROSS SLABS (the multi-GPU half): every slab keeps its rows in the registers of its
+// own GPU for the whole run, and the granules that leave a slab through its bottom / top edge go straight into the
+// neighbouring slab's mailboxes (lbm_regtile.hip.h, kRegSlab) -- over xGMI when that slab lives on another GPU.  Same
+// tiling on every slab (equal slabs, 64-column tiles of ty rows); the slabs of one device go in ONE launch (their tiles
+// wait for each other, so they must be resident together).  Contexts whose neighbours can store into each other's
+// memory: slabs of one process (copy and peer-to-peer contexts: pointers, peer access across devices), and one process
+// per GPU with peer-to-peer halos (hipIpc mappings, handles in the halo block; needs the communicator, through which the
+// ranks agree after every run whether anybody gave up).
+int regtile_slab_count(const lbm_ctx* c) { return c->rank_mode ? c->nranks : (int)c->slabs.size(); }
+
+bool regtile_slabs_possible(const lbm_ctx* c) {
+  if (c->exchange != LBM_EXCHANGE_P2P && c->exchange != LBM_EXCHANGE_COPY) return false;
+  // (ranks without a communicator cannot agree on whether anybody gave up: the streaming kernels, unless a test that adds up
+  // the ranks' results itself says otherwise)
+  static const bool trust = getenv("LBM_REGTILE_SLABS_NO_AGREEMENT") && atoi(getenv("LBM_REGTILE_SLABS_NO_AGREEMENT"));
+  if (c->rank_mode && c->nranks > 1 && ((c->no_comm && !trust) || c->exchange != LBM_EXCHANGE_P2P)) return false;
+  const int n = regtile_slab_count(c);
+  return c->p.nx % 64 == 0 && n >= 1 && c->p.ny % n == 0;
+}
+
+// Tiling: as for a lattice alone (as few rows per wave as fit, on at most half the CUs where possible), counted per device.
+bool plan_regtile_slabs(lbm_ctx* c) {
+  c->splan.ty = 0;
+  if (!regtile_slabs_possible(c)) return false;
+  const char* off = getenv("LBM_REGTILE_SLABS");
+  if (off && atoi(off) == 0) return false;
+  const int nyl = c->p.ny / regtile_slab_count(c);
+  int per_dev = 1;
+  for (auto& a : c->slabs) {
+    int n = 0;
+    for (auto& b : c->slabs) n += (b.dev == a.dev) ? 1 : 0;
+    per_dev = std::max(per_dev, n);
+  }
+  const long ntx = c->p.nx / 64;
+  for (long limit : {(long)c->ncu / 2, (long)c->ncu})
+    for (int r : {1, 2, 4})
+      for (int ty = r; ty <= std::min(nyl, 16 * r); ty += r) {
+        if (nyl % ty != 0) continue;
+        const int nw = ty / r;
+        const int lds_per_cu = (160 * 1024) / lbm::regtile_lds_bytes(nw, r);
+        if (lds_per_cu < 1) continue;
+        if (per_dev * ntx * (nyl / ty) > limit) continue;
+        c->splan.ty = ty; c->splan.r = r; c->splan.nw = nw; c->splan.ntx = (int)ntx; c->splan.nty = nyl / ty; c->splan.bpc = 0;
+        return true;
+      }
+  return false;
+}
+
+typedef void (*regtile_slabs_fn)(const lbm::RegTileArgs*);
+regtile_slabs_fn regtile_slabs_kernel(int r, bool fast, bool async) {
+  constexpr int AS_ = lbm::kRegAsync, SL_ = lbm::kRegSlab;
+  if (async && r == 4) return fast ? lbm::lbm_regtile_slabs<4, SL_ | AS_ | 1> : lbm::lbm_regtile_slabs<4, SL_ | AS_>;
+  if (async && r == 2) return fast ? lbm::lbm_regtile_slabs<2, SL_ | AS_ | 1> : lbm::lbm_regtile_slabs<2, SL_ | AS_>;
+  switch (r) {
+    case 4: return fast ? lbm::lbm_regtile_slabs<4, SL_ | 1> : lbm::lbm_regtile_slabs<4, SL_>;
+    case 2: return fast ? lbm::lbm_regtile_slabs<2, SL_ | 1> : lbm::lbm_regtile_slabs<2, SL_>;
+    default: return fast ? lbm::lbm_regtile_slabs<1, SL_ | 1> : lbm::lbm_regtile_slabs<1, SL_>;
+  }
+}
+
+size_t regtile_slab_mail_bytes(const lbm_ctx* c) {
+  return (size_t)c->splan.ntx * c->splan.nty * 2 * (size_t)lbm::regtile_box(c->splan.ty);
+}
+
+// A slab's mail area.  Uncached device memory, like the peer-to-peer halo blocks: a neighbour on another GPU stores into it
+// behind this GPU's L2 (LBM_REGTILE_MAIL_CACHED=1: ordinary device memory, to measure what that costs on one GPU).
+int regtile_slab_mail_alloc(lbm_ctx* c, Slab& s) {
+  if (s.tmail) return LBM_OK;
+  HIPC(hipSetDevice(s.dev));
+  const size_t bytes = regtile_slab_mail_bytes(c);
+  static const bool cached = getenv("LBM_REGTILE_MAIL_CACHED") && atoi(getenv("LBM_REGTILE_MAIL_CACHED"));
+  hipError_t e = cached ? hipMalloc((void**)&s.tmail, bytes) : hipExtMallocWithFlags((void**)&s.tmail, bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) { (void)hipGetLastError(); s.tmail = nullptr; return fail(LBM_EHIP, "cannot allocate the mail area of a slab: %s", hipGetErrorString(e)); }
+  HIPC(hipMemset(s.tmail, 0, bytes));
+  HIPC(hipDeviceSynchronize());
+  s.tmail_bytes = bytes;
+  return LBM_OK;
+}
+
+void regtile_slabs_free(lbm_ctx* c) {
+  for (auto& s : c->slabs) {
+    (void)hipSetDevice(s.dev);
+    for (int side = 0; side < 2; ++side) {
+      if (s.tmail_nb_ipc[side] && s.tmail_nb[side] && (side == 0 || s.tmail_nb[1] != s.tmail_nb[0])) (void)hipIpcCloseMemHandle(s.tmail_nb[side]);
+      s.tmail_nb[side] = nullptr; s.tmail_nb_ipc[side] = false;
+    }
+    if (s.tmail) (void)hipFree(s.tmail);
+    if (s.rpartials) (void)hipFree(s.rpartials);
+    if (s.rabort) (void)hipFree(s.rabort);
+    if (s.ev_rt) (void)hipEventDestroy(s.ev_rt);
+    s.tmail = nullptr; s.rpartials = nullptr; s.rabort = nullptr; s.ev_rt = nullptr; s.rpartials_cap = 0;
+  }
+  if (c->rtable) (void)hipHostFree(c->rtable);
+  c->rtable = c->rtable_dev = nullptr;
+}
+
+bool regtile_slabs_usable(const lbm_ctx* c) {
+  if (c->splan.ty <= 0 || c->resident_broken || (c->variant & 8) != 0 || !(c->engine == 0 || c->engine == 3)) return false;
+  if (!regtile_slabs_possible(c)) return false;
+  if (c->rank_mode && c->nranks > 1) {
+    if (!c->p2p_connected) return false;
+    for (int side = 0; side < 2; ++side) if (!c->slabs[0].tmail_nb[side]) return false;
+  }
+  return true;
+}
+
+int run_regtile_slabs(lbm_ctx* c, int nsteps, float* av_vels, bool* done) {
+  *done = false;
+  const auto& t = c->splan;
+  const int ns = (int)c->slabs.size(), ntiles = t.ntx * t.nty;
+  const bool fast = (c->variant & lbm::kFastMath) != 0;
+  const dim3 block(64 * t.nw);
+  const unsigned shm = (unsigned)lbm::regtile_lds_bytes(t.nw, t.r);
+  const regtile_slabs_fn fn = regtile_slabs_kernel(t.r, fast, c->regtile_async != 0);
+  int rc;
+  // device groups: the local slabs in the order of their devices' first appearance
+  std::vector<int> order, gstart;          // order[k] = slab index; gstart[g] = first k of group g (+ end)
+  {
+    std::vector<bool> taken(ns, false);
+    for (int i = 0; i < ns; ++i) {
+      if (taken[i]) continue;
+      gstart.push_back((int)order.size());
+      for (int j = i; j < ns; ++j) if (!taken[j] && c->slabs[j].dev == c->slabs[i].dev) { taken[j] = true; order.push_back(j); }
+    }
+    gstart.push_back((int)order.size());
+  }
+  const int ngroups = (int)gstart.size() - 1;
+  if (c->splan.bpc == 0) {           // first run: is every tile of every device resident at once?
+    int worst = 1 << 30, most = 1;
+    for (int g = 0; g < ngroups; ++g) {
+      Slab& l = c->slabs[order[gstart[g]]];
+      HIPC(hipSetDevice(l.dev));
+      const int n = regtile_prepare(c, reinterpret_cast<const void*>(fn), l.dev, (int)block.x, shm);
+      if (n < 0) { c->splan.bpc = -1; snprintf(c->resident_why, sizeof(c->resident_why), "%s", lbm_last_error()); break; }
+      worst = std::min(worst, n); most = std::max(most, gstart[g + 1] - gstart[g]);
+    }
+    if (c->splan.bpc == 0) {
+      c->splan.bpc = worst;
+      if ((long)worst * std::max(c->ncu, 1) < (long)ntiles * most) {
+        c->splan.bpc = -1;
+        snprintf(c->resident_why, sizeof(c->resident_why), "%d slabs x %d tiles of %d waves on one device, but it takes %d block(s) per CU on %d CUs at once", most, ntiles, t.nw, worst, c->ncu);
+      }
+    }
+  }
+  if (c->splan.bpc < 0) return fail(LBM_EINVAL, "register tiling across slabs not usable: %s", c->resident_why);
+  // peer access between the devices of neighbouring slabs (one process)
+  if (!c->rank_mode)
+    for (int i = 0; i < ns; ++i)
+      for (int d : {(i + ns - 1) % ns, (i + 1) % ns}) {
+        const int a = c->slabs[i].dev, b = c->slabs[d].dev;
+        if (a == b) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) { (void)hipGetLastError(); return fail(LBM_EHIP, "device %d cannot store into device %d", a, b); }
+        HIPC(hipSetDevice(a));
+        const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+        (void)hipGetLastError();
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(LBM_EHIP, "hipDeviceEnablePeerAccess(%d -> %d): %s", a, b, hipGetErrorString(e));
+      }
+  for (auto& s : c->slabs) {
+    if ((rc = regtile_slab_mail_alloc(c, s))) return rc;
+    HIPC(hipSetDevice(s.dev));
+    if (!s.ev_rt) HIPC(hipEventCreateWithFlags(&s.ev_rt, hipEventDisableTiming));
+    if (s.rpartials_cap < nsteps) {
+      long cap = std::max(1024L, s.rpartials_cap);
+      while (cap < nsteps) cap *= 2;
+      if (s.rpartials) HIPC(hipFree(s.rpartials));
+      s.rpartials = nullptr; s.rpartials_cap = 0;
+      HIPC(hipMalloc((void**)&s.rpartials, sizeof(float) * (size_t)cap * ntiles));
+      s.rpartials_cap = cap;
+    }
+    if ((rc = ensure_sums(s, nsteps + 1))) return rc;
+  }
+  for (int g = 0; g < ngroups; ++g) {
+    Slab& l = c->slabs[order[gstart[g]]];
+    if (!l.rabort) {
+      HIPC(hipSetDevice(l.dev));
+      HIPC(hipMalloc((void**)&l.rabort, 64));
+      HIPC(hipMemset(l.rabort, 0, 64));
+    }
+  }
+  if (!c->rtable) {
+    HIPC(hipHostMalloc((void**)&c->rtable, sizeof(lbm::RegTileArgs) * ns, hipHostMallocPortable | hipHostMallocMapped));
+    HIPC(hipHostGetDevicePointer((void**)&c->rtable_dev, c->rtable, 0));
+  }
+  // tags: as for a lattice alone; every slab (every rank) counts the same runs, so all hold the same tag0
+  if ((unsigned long long)c->rtag + (unsigned long long)nsteps >= 0x7fffff00ull)
+    return fail(LBM_EINVAL, "mailbox tags of the slabs exhausted (2^31 steps on one context)");
+  for (int g = 0; g < ngroups; ++g)
+    for (int k = gstart[g]; k < gstart[g + 1]; ++k) {
+      const int i = order[k];
+      Slab& s = c->slabs[i];
+      lbm::RegTileArgs& a = c->rtable[k];
+      a.src = s.lat[c->cur]; a.dst = s.lat[c->cur ^ 1];
+      a.plane = s.plane; a.pitch = s.pitch; a.nx = c->p.nx; a.ny = s.nyl;
+      a.blocked = s.blocked; a.omega = c->p.omega;
+      a.accel_row = s.accel_row;
+      a.a1 = c->p.density * c->p.accel / 9.f; a.a2 = c->p.density * c->p.accel / 36.f;
+      a.ty = t.ty; a.ntx = t.ntx; a.nty = t.nty;
+      a.nsteps = nsteps; a.tag0 = c->rtag;
+      a.mail = s.tmail; a.mail_bytes = (unsigned)s.tmail_bytes;
+      a.partials = s.rpartials; a.abort_word = c->slabs[order[gstart[g]]].rabort;
+      a.fault = (getenv("LBM_REGTILE_FAULT") && i == 0) ? 1 : 0;
+      a.stats = nullptr;
+      if (c->rank_mode && c->nranks > 1) {
+        a.mail_s = s.tmail_nb[0]; a.mail_n = s.tmail_nb[1];
+        a.mail_bytes_s = (unsigned)s.tmail_nb_bytes[0]; a.mail_bytes_n = (unsigned)s.tmail_nb_bytes[1];
+      } else {                        // (one process, or a ring of one rank: the neighbours are local slabs)
+        Slab& so = c->slabs[(i + ns - 1) % ns];
+        Slab& no = c->slabs[(i + 1) % ns];
+        a.mail_s = so.tmail; a.mail_n = no.tmail;
+        a.mail_bytes_s = (unsigned)so.tmail_bytes; a.mail_bytes_n = (unsigned)no.tmail_bytes;
+      }
+      a.nty_s = t.nty; a.nty_n = t.nty;
+    }
+  c->rtag += (uint32_t)nsteps + 1u;
+  const auto wall0 = std::chrono::steady_clock::now();
+  for (auto& s : c->slabs) {
+    HIPC(hipSetDevice(s.dev));
+    s.err_host[1] = 0;
+    HIPC(hipEventRecord(s.ev_t0, s.sc));
+  }
+  for (int g = 0; g < ngroups; ++g) {
+    Slab& l = c->slabs[order[gstart[g]]];
+    HIPC(hipSetDevice(l.dev));
+    for (int k = gstart[g] + 1; k < gstart[g + 1]; ++k) HIPC(hipStreamWaitEvent(l.sc, c->slabs[order[k]].ev_t0, 0));
+    hipLaunchKernelGGL(fn, dim3(ntiles, gstart[g + 1] - gstart[g]), block, shm, l.sc, c->rtable_dev + gstart[g]);
+    HIPC(hipGetLastError());
+    HIPC(hipEventRecord(l.ev_rt, l.sc));
+    for (int k = gstart[g]; k < gstart[g + 1]; ++k) {
+      Slab& s = c->slabs[order[k]];
+      if (k > gstart[g]) HIPC(hipStreamWaitEvent(s.sc, l.ev_rt, 0));
+      hipLaunchKernelGGL(lbm::lbm_fold_steps, dim3(cdiv(nsteps, lbm::kBlock / 64)), dim3(lbm::kBlock), 0, s.sc,
+                         s.rpartials, ntiles, nsteps, s.sums, l.rabort, s.err_host + 1);
+      HIPC(hipGetLastError());
+      HIPC(hipEventRecord(s.ev_t1, s.sc));
+    }
+  }
+  // did anybody give up?  One process: the abort words are all here.  One process per GPU: the ranks must agree (a rank whose
+  // neighbour stopped notices a second later; one far away in a short run might not at all), so the word rides as one more
+  // double behind the per-step sums through the all-reduce that ends the run.
+  const bool agree = c->rank_mode && c->slabs[0].comm != nullptr;
+  if (agree) {
+    Slab& s = c->slabs[0];
+    hipLaunchKernelGGL(lbm::lbm_abort_to_sum, dim3(1), dim3(64), 0, s.sc, s.rabort, s.sums + nsteps);
+    HIPC(hipGetLastError());
+  }
+  rc = collect_sums(c, nsteps, av_vels, wall0, agree ? 1 : 0);
+  if (rc) return rc;
+  bool gave_up = false;
+  for (auto& s : c->slabs) gave_up = gave_up || s.err_host[1] != 0;
+  if (agree) gave_up = gave_up || c->slabs[0].sums_host[nsteps] != 0.0;
+  if (gave_up) {
+    for (int g = 0; g < ngroups; ++g) {
+      Slab& l = c->slabs[order[gstart[g]]];
+      HIPC(hipSetDevice(l.dev));
+      HIPC(hipMemsetAsync(l.rabort, 0, 64, l.sc));
+      HIPC(hipStreamSynchronize(l.sc));
+    }
+    resident_give_up(c, "a tile waited 1 s for a neighbour (register tiles across slabs): not every tile was running at once");
     return LBM_OK;
   }
   c->cur ^= 1;
@@ -2265,7 +2584,20 @@ extern "C" int lbm_run(lbm_ctx* c, int nsteps, float* av_vels) {
   const int nx = c->p.nx;
   const float a1 = c->p.density * c->p.accel / 9.f;   // d2q9-bgk.c:230-231
   const float a2 = c->p.density * c->p.accel / 36.f;
-  if (c->exchange == LBM_EXCHANGE_P2P) return run_p2p(c, nsteps, av_vels);
+  if (c->exchange != 0 && regtile_slabs_usable(c)) {
+    bool done = false;
+    int rr = run_regtile_slabs(c, nsteps, av_vels, &done);
+    if (rr && c->engine == 0) {          // (as below: set-up failures of the automatic engine are not the caller's problem)
+      (void)hipGetLastError();
+      resident_give_up(c, lbm_last_error());
+      rr = LBM_OK;
+    }
+    if (rr) return rr;
+    if (done) { c->engine_last = 3; return LBM_OK; }
+  }
+  if (c->exchange != 0 && c->engine >= 2) return fail(LBM_EINVAL, "register tiles across slabs cannot run here (%s) (engine = %d)",
+                                                      c->resident_why[0] ? c->resident_why : "no tiling", c->engine);
+  if (c->exchange == LBM_EXCHANGE_P2P) { c->engine_last = 1; return run_p2p(c, nsteps, av_vels); }
   if (c->exchange == 0 && c->slabs.size() == 1 && (c->engine == 3 || c->engine == 0) && c->tplan.ty > 0 && !c->resident_broken &&
       (c->variant & 8) == 0) {
     bool done = false;
@@ -2522,6 +2854,7 @@ extern "C" int lbm_final_state(lbm_ctx* c, float* out) {
 extern "C" int lbm_destroy(lbm_ctx* c) {
   if (!c) return LBM_OK;
   resident_free(c);
+  regtile_slabs_free(c);
   for (auto& s : c->slabs) slab_free(s);
   delete c;
   return LBM_OK;
@@ -2602,16 +2935,23 @@ extern "C" int lbm_set_option(lbm_ctx* c, const char* key, long value) {
   if (!strcmp(key, "engine")) {
     if (value != 0 && value != 1 && value != 3)
       return fail(LBM_EINVAL, "engine must be 0 (auto), 1 (streaming kernels) or 3 (resident in registers); 2, the LDS-resident engine, was removed");
-    if (value == 3 && (c->exchange != 0 || c->slabs.size() != 1 || c->tplan.ty == 0))
+    if (value == 3 && c->exchange != 0 && c->splan.ty == 0)
+      return fail(LBM_EINVAL, "register tiles across slabs need equal slabs that tile onto the CUs and neighbours that can store into each other's memory");
+    if (value == 3 && c->exchange == 0 && (c->slabs.size() != 1 || c->tplan.ty == 0))
       return fail(LBM_EINVAL, "the resident kernel needs a lattice alone on its GPU that tiles onto the CUs");
     c->engine = (int)value;
-    if (value == 3) { c->resident_broken = false; c->resident_why[0] = 0; if (c->tplan.bpc < 0) c->tplan.bpc = 0; }
+    if (value == 3) {
+      c->resident_broken = false; c->resident_why[0] = 0;
+      if (c->tplan.bpc < 0) c->tplan.bpc = 0;
+      if (c->splan.bpc < 0) c->splan.bpc = 0;
+    }
     return LBM_OK;
   }
   if (!strcmp(key, "regtile_async")) {
     if (value != 0 && value != 1) return fail(LBM_EINVAL, "regtile_async must be 0 or 1");
     c->regtile_async = (int)value;
     c->tplan.bpc = c->tplan.bpc < 0 ? c->tplan.bpc : 0;     // (another instantiation: ask about its residency again)
+    c->splan.bpc = c->splan.bpc < 0 ? c->splan.bpc : 0;
     return LBM_OK;
   }
   if (!strcmp(key, "regtile")) {   // rows per tile * 10 + rows per wave
@@ -2652,14 +2992,15 @@ extern "C" int lbm_get_info(const lbm_ctx* c, const char* key, double* value) {
   if (!strcmp(key, "engine")) { *value = c->engine; return LBM_OK; }
   if (!strcmp(key, "engine_last")) { *value = c->engine_last; return LBM_OK; }
   if (!strcmp(key, "engine_next")) {   // what the next lbm_run will try first
-    *value = (c->exchange == 0 && c->slabs.size() == 1 && !c->resident_broken)
+    if (c->exchange != 0) *value = regtile_slabs_usable(c) ? 3 : 1;
+    else *value = (c->slabs.size() == 1 && !c->resident_broken)
                  ? (((c->engine == 3 || c->engine == 0) && c->tplan.ty > 0 && (c->variant & 8) == 0) ? 3 : 1) : 1;
     return LBM_OK;
   }
   if (!strcmp(key, "resident_fallback")) { *value = c->resident_broken ? 1 : 0; return LBM_OK; }   // 1: the resident kernel could not run here
-  if (!strcmp(key, "regtile_blocks_per_cu")) { *value = c->tplan.bpc; return LBM_OK; }              // occupancy answer (0: not asked yet)
+  if (!strcmp(key, "regtile_blocks_per_cu")) { *value = c->exchange != 0 ? c->splan.bpc : c->tplan.bpc; return LBM_OK; }   // occupancy answer (0: not asked yet)
   if (!strcmp(key, "compute_units")) { *value = c->ncu; return LBM_OK; }
-  if (!strcmp(key, "regtile")) { *value = c->tplan.ty * 10.0 + c->tplan.r; return LBM_OK; }
+  if (!strcmp(key, "regtile")) { *value = c->exchange != 0 ? c->splan.ty * 10.0 + c->splan.r : c->tplan.ty * 10.0 + c->tplan.r; return LBM_OK; }
   if (!strcmp(key, "regtile_async")) { *value = c->regtile_async; return LBM_OK; }
   if (!strcmp(key, "exchange")) { *value = c->exchange; return LBM_OK; }
   if (!strcmp(key, "pitch")) { *value = c->slabs[0].pitch; return LBM_OK; }

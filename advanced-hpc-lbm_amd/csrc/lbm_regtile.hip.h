@@ -51,6 +51,8 @@ constexpr long long kResidentTimeoutTicks = 100000000LL;       // a wait for mai
 // timing experiments only (wrong results): LBM_RESIDENT_DEBUG=1 never waits for a tag, 2 also sends nothing
 constexpr int kResDebugNoWait = 64, kResDebugNoSend = 128;
 constexpr int kRegAsync = 4096;   // lbm_regtile: mail loads / stores of the loop as inline asm with counted s_waitcnt vmcnt(N)
+constexpr int kRegSlab = 8192;    // lbm_regtile: the lattice is a slab with neighbours -- the tile rows below its first and above its
+                                  // last belong to OTHER slabs (same tiling), whose mailboxes live in their own mail areas
 typedef __attribute__((address_space(1))) unsigned int gu32;
 
 // Per-step sums of a whole-run launch: partials[step][tile] -> sums[step] (double, fixed order), one wave per step; also
@@ -68,6 +70,12 @@ __global__ __launch_bounds__(kBlock) void lbm_fold_steps(const float* partials, 
   if (lane == 0) sums[step] = s;
 }
 
+// one process per GPU: the abort word of a run as one more double behind the per-step sums (the all-reduce that ends the
+// run then tells every rank whether ANY rank gave up)
+__global__ void lbm_abort_to_sum(const uint32_t* abort_word, double* out) {
+  if (threadIdx.x == 0) *out = (*abort_word != 0u) ? 1.0 : 0.0;
+}
+
 struct RegTileArgs {
   const float* src; float* dst; long plane; int pitch, nx, ny;
   const uint8_t* blocked;
@@ -82,6 +90,13 @@ struct RegTileArgs {
   uint32_t* abort_word;
   int fault;                   // test hook: tile 0 never starts (its neighbours time out, the host falls back)
   unsigned long long* stats;   // development: [0] += waits that found their mail missing, [1] += extra fetches (or nullptr)
+  // ---- a slab with neighbours (MODE & kRegSlab; launched through lbm_regtile_slabs): `ny` rows and `nty` tile rows are this
+  // slab's; the granules that leave through its bottom / top edge go into the mail area of the slab to the south / north
+  // (same process: its pointer, with peer access when it lives on another GPU; other process: a hipIpc mapping), whose
+  // tile rows are numbered 0 .. nty_s-1 / nty_n-1 with the same 64-column x ty-row tiles.  What ARRIVES is always in `mail`.
+  void* mail_s; void* mail_n;
+  unsigned mail_bytes_s, mail_bytes_n;
+  int nty_s, nty_n;
 };
 
 // LDS bytes of a block of nw waves with r rows per wave (see the kernel)
@@ -109,8 +124,9 @@ template <int N> __device__ __forceinline__ float rt_row_shr(unsigned v) {
 
 // blockDim.x = 64 NW; R rows per wave.
 template <int R, int MODE>
-__global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
+__device__ __forceinline__ void regtile_body(const RegTileArgs& a) {
   constexpr bool FAST = (MODE & kFastMath) != 0;
+  constexpr bool SLAB = (MODE & kRegSlab) != 0;
   // timing experiments only (wrong results), LBM_RESIDENT_DEBUG: 1 = one pass over the inbox, no waiting; 2 = also no
   // stores to other tiles; 3 = also no inbox loads at all; 4 = like 1, the stores issued but dropped by an empty buffer
   // descriptor (what the instructions cost without their memory traffic); 5 = like 1, stores without sc1
@@ -137,22 +153,36 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
   const int by = tile / a.ntx, bx = tile - by * a.ntx;
   const int TY = a.ty;
   const unsigned BOX = (unsigned)regtile_box(TY);
+  // (a slab: the row below tile row 0 is the LAST tile row of the slab to the south, numbered in that slab's mail area; the
+  // row above the last is row 0 of the slab to the north -- see `south_out` / `north_out` for where such granules are sent)
   auto tile_of = [&](int dx, int dy) {
     int x = bx + dx, y = by + dy;
     x += (x < 0) ? a.ntx : 0; x -= (x >= a.ntx) ? a.ntx : 0;
-    y += (y < 0) ? a.nty : 0; y -= (y >= a.nty) ? a.nty : 0;
+    y += (y < 0) ? (SLAB ? a.nty_s : a.nty) : 0; y -= (y >= a.nty) ? a.nty : 0;
     return y * a.ntx + x;
   };
   // mailbox sections (byte offsets inside a box); the whole mail area is a few MB: 32-bit offsets behind one descriptor
   const unsigned oS = 0u, oN = 1024u, oW = 2048u, oE = 2048u + 16u * (unsigned)(TY + 2);
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.mail, 0, (int)a.mail_bytes, 0x00020000);
   const auto rsrc_st = DBG_DROP ? __builtin_amdgcn_make_buffer_rsrc(a.mail, 0, 0, 0x00020000) : rsrc;
+  // where the granules that leave through the tile's bottom / top edge (and the two corners on that side) are stored: this
+  // slab's mail area, or the neighbouring slab's for the slab's first / last tile row (wave-uniform, fixed for the run)
+  const bool south_out = SLAB && by == 0, north_out = SLAB && by == a.nty - 1;
+  const auto rsrc_s = south_out ? __builtin_amdgcn_make_buffer_rsrc(a.mail_s, 0, (int)a.mail_bytes_s, 0x00020000) : rsrc_st;
+  const auto rsrc_n = north_out ? __builtin_amdgcn_make_buffer_rsrc(a.mail_n, 0, (int)a.mail_bytes_n, 0x00020000) : rsrc_st;
+  using ToOwn = std::integral_constant<int, 0>;
+  using ToSouth = std::integral_constant<int, 1>;
+  using ToNorth = std::integral_constant<int, 2>;
   auto box = [&](int t) { return (unsigned)(t * 2) * BOX; };            // parity 0; parity 1: + BOX
   // (per-lane offset in a register, wave-uniform offset in the instruction's scalar operand: one register per KIND of access)
-  auto send = [&](unsigned voff, unsigned soff, float v0, float v1, float v2, uint32_t tag) {
+  // (granules for another slab: sc0 sc1 = system scope, the neighbour may live on another GPU)
+  auto send = [&](auto to, unsigned voff, unsigned soff, float v0, float v1, float v2, uint32_t tag) {
+    constexpr int TO = decltype(to)::value;
     rt_u4 g;
     g.x = __float_as_uint(v0); g.y = __float_as_uint(v1); g.z = __float_as_uint(v2); g.w = tag;
-    if (!DBG_NOSEND) __builtin_amdgcn_raw_buffer_store_b128(g, rsrc_st, voff, soff, DBG_PLAIN ? 0 : 16);      // aux 16 = sc1
+    if (DBG_NOSEND) return;
+    if constexpr (!SLAB || TO == 0) __builtin_amdgcn_raw_buffer_store_b128(g, rsrc_st, voff, soff, DBG_PLAIN ? 0 : 16);      // aux 16 = sc1
+    else __builtin_amdgcn_raw_buffer_store_b128(g, TO == 1 ? rsrc_s : rsrc_n, voff, soff, 17);
   };
   auto load = [&](unsigned voff, unsigned soff) { return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 16); };
   const int tS = tile_of(0, -1), tN = tile_of(0, 1), tW = tile_of(-1, 0), tE = tile_of(1, 0);
@@ -173,8 +203,10 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
   const bool courier = (lane < 3) || (lane > 60);
   // The mail LOADS of the loop are issued by every lane of every wave, unconditionally: the lanes (and waves) a load
   // does not concern carry an offset beyond the end of the buffer, and the descriptor's range check answers them
-  // with zeros.  The STORES stay behind their branches (lanes 0 and 63, the tile's first and last wave): with stores
-  // masked the same way the lattice came out wrong once a SIMD held more than one wave of the tile.  A branch with a
+  // with zeros.  In THIS (compiler-scheduled) loop the STORES stay behind their branches (lanes 0 and 63, the tile's first
+  // and last wave): one build of it with every store masked the same way hung on multi-wave tiles and the next build,
+  // different only by diagnostic code, passed -- a property of one instruction schedule, not of masked stores (the
+  // asynchronous loop below uses nothing else; tools/oob_store_order probes the hardware).  A branch with a
   // memory operation in it makes the compiler wait for ALL outstanding memory operations (s_waitcnt vmcnt(0)) the
   // next time a loaded value is used behind it, acknowledgements of the sc1 stores included (~1500 cycles) -- so
   // a row's granules are sent only once the NEXT row's mail has been waited for (do_row): no load is ever in flight
@@ -203,13 +235,13 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
     const bool wl = lane == 0;
     const float v0 = wl ? w3 : e1, v1 = wl ? w6 : e5, v2 = wl ? w7 : e8;
     if (r == 0 && first)             // the tile's bottom row enters the tile below through ITS north inbox
-      send(lane16, box(tS) + oN + pb, q[4], q[7], q[8], tag);
+      send(ToSouth{}, lane16, box(tS) + oN + pb, q[4], q[7], q[8], tag);
     if (r == R - 1 && last)
-      send(lane16, box(tN) + oS + pb, q[2], q[5], q[6], tag);
-    if (edge_lane) send(ew_voff, pb + 16u * r, v0, v1, v2, tag);
+      send(ToNorth{}, lane16, box(tN) + oS + pb, q[2], q[5], q[6], tag);
+    if (edge_lane) send(ToOwn{}, ew_voff, pb + 16u * r, v0, v1, v2, tag);
     // the tile's corners: the same granule is row -1 / row TY of the diagonal tile's inbox
-    if (r == R - 1 && last && edge_lane) send(cn_voff, pb, v0, v1, v2, tag);
-    if (r == 0 && first && edge_lane) send(cs_voff, pb, v0, v1, v2, tag);
+    if (r == R - 1 && last && edge_lane) send(ToNorth{}, cn_voff, pb, v0, v1, v2, tag);
+    if (r == 0 && first && edge_lane) send(ToSouth{}, cs_voff, pb, v0, v1, v2, tag);
   };
   // the edge rows of the state in f for the neighbouring waves: bottom row's planes 4,7,8, top row's 2,5,6
   auto publish_lds = [&](int parity) {
@@ -377,11 +409,17 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
       // tools/audit_regtile_isa.py checks the five instructions in front of every one of these for a VALU write to them)
       asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen sc1" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
     };
-    auto astore = [&](unsigned voff, unsigned soff, float v0, float v1, float v2, uint32_t tag) {
+    auto astore = [&](auto to, unsigned voff, unsigned soff, float v0, float v1, float v2, uint32_t tag) {
+      constexpr int TO = decltype(to)::value;
       rt_u4 g;
       g.x = __float_as_uint(v0); g.y = __float_as_uint(v1); g.z = __float_as_uint(v2); g.w = tag;
-      const auto rs = rsrc;
-      asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 1" :: "v"(g), "v"(voff), "s"(rs), "s"(soff) : "memory");
+      if constexpr (!SLAB || TO == 0) {
+        const auto rs = rsrc;
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 1" :: "v"(g), "v"(voff), "s"(rs), "s"(soff) : "memory");
+      } else {
+        const auto rs = (TO == 1) ? rsrc_s : rsrc_n;
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc0 sc1\n\ts_nop 1" :: "v"(g), "v"(voff), "s"(rs), "s"(soff) : "memory");
+      }
     };
     auto afetch = [&](auto rc, unsigned pbx, Slot& m) {
       constexpr int r = decltype(rc)::value;
@@ -526,14 +564,14 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
           {
             const bool wl = lane == 0;
             const float v0 = wl ? p[3] : p[1], v1 = wl ? p[6] : p[5], v2 = wl ? p[7] : p[8];
-            astore(ew_m, pbn + 16u * r, v0, v1, v2, tagn);
+            astore(ToOwn{}, ew_m, pbn + 16u * r, v0, v1, v2, tagn);
             if constexpr (r == 0) {
-              astore(first_voff, boxS + pbn, p[4], p[7], p[8], tagn);
-              astore(cs_m, pbn, v0, v1, v2, tagn);
+              astore(ToSouth{}, first_voff, boxS + pbn, p[4], p[7], p[8], tagn);
+              astore(ToSouth{}, cs_m, pbn, v0, v1, v2, tagn);
             }
             if constexpr (r == R - 1) {
-              astore(last_voff, boxN + pbn, p[2], p[5], p[6], tagn);
-              astore(cn_m, pbn, v0, v1, v2, tagn);
+              astore(ToNorth{}, last_voff, boxN + pbn, p[2], p[5], p[6], tagn);
+              astore(ToNorth{}, cn_m, pbn, v0, v1, v2, tagn);
             }
           }
           __builtin_amdgcn_sched_barrier(0);           // one row at a time
@@ -726,6 +764,29 @@ __global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
     v = wave_sum(v);
     if (tid == 0) a.partials[(long)(a.nsteps - 1) * nt + tile] = v;
   }
+}
+
+// A lattice alone on its GPU: gridDim.x = its tiles.
+template <int R, int MODE>
+__global__ __launch_bounds__(1024) void lbm_regtile(const RegTileArgs a) {
+  regtile_body<R, MODE>(a);
+}
+
+// The slabs of ONE device in ONE launch (MODE & kRegSlab): gridDim.x = tiles per slab, gridDim.y = slabs of this device,
+// table[blockIdx.y] = that slab's arguments.  One launch, because tiles of different slabs wait for each other exactly as
+// tiles of one slab do: they must all be resident at once, which separate launches on separate streams do not promise.
+// (The table is read through the constant address space: scalar loads, the arguments live in SGPRs as kernel arguments do.)
+template <int R, int MODE>
+__global__ __launch_bounds__(1024) void lbm_regtile_slabs(const RegTileArgs* table) {
+  static_assert((MODE & kRegSlab) != 0, "slab flavour");
+  typedef const __attribute__((address_space(4))) unsigned* cwords_t;
+  static_assert(sizeof(RegTileArgs) % 4 == 0, "copied word by word");
+  const cwords_t src = (cwords_t)(unsigned long long)(table + blockIdx.y);
+  RegTileArgs a;
+  unsigned* dst = reinterpret_cast<unsigned*>(&a);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(RegTileArgs) / 4); ++i) dst[i] = src[i];
+  regtile_body<R, MODE>(a);
 }
 
 }  // namespace lbm

@@ -1441,6 +1441,183 @@ def test_register_tile_asynchronous_loop_equals_single_step_kernel(gpu, tile, nx
 # (nx, ny, slabs on one GPU, transport) -> (engine the next run tries first: 3 = lbm_regtile, 1 = streaming kernels;
 #  steps per pass; 1 = lbm_wave rather than lbm_march; columns per lane of lbm_wave).  Written by tools/selection_table.py on an
 # MI355X (256 CUs); "rccl" = one rank of a RCCL job as a ring of one.
+# ---------------------------------------------------------------------------------------------------------------
+# Register tiles ACROSS SLABS (the multi-GPU half): every slab's rows stay in the registers
+# of its GPU, the granules that leave a slab go straight into the neighbouring slab's mailboxes.
+
+@pytest.mark.parametrize("exchange", ["copy", "p2p"])
+@pytest.mark.parametrize("case,nslabs,steps", [
+    ("1024x1024", 2, [33, 4]), ("1024x1024", 4, [21]), ("1024x1024", 8, [40, 1, 6]), ("256x256", 4, [50]), ("128x128", 2, [31, 2]),
+    ("128x256", 8, [17]), ((192, 96), 3, [12, 7]), ((64, 64), 4, [9]), ((320, 48), 2, [5, 5]),
+])
+def test_register_tiles_across_slabs_of_one_process(gpu, exchange, case, nslabs, steps):
+    """The slabs of one process (all on this GPU, so all in ONE launch: gridDim.y = slabs): lbm_regtile_slabs against the
+    one-step kernel on the undivided lattice -- bit-identical lattice, av_vels to summation order; engine_last says it ran."""
+    L = gpu
+    if isinstance(case, str):
+        pf, of = deck_paths(case)
+        p = L.read_params(pf)
+        ob = L.read_obstacles(of, p)
+        cells = None
+    else:
+        p, ob, cells = _random_case(L, case[0], case[1], 5)
+    with L.Lattice(p, ob, cells) as lat:
+        lat.set_option("time_block", 1)
+        av1 = np.concatenate([lat.run(n) for n in steps])
+        st1 = lat.read_state()
+    ex = L.EXCHANGE_COPY if exchange == "copy" else L.EXCHANGE_P2P
+    with L.Lattice(p, ob, cells, nslabs=nslabs, devices=[0] * nslabs, exchange=ex) as lat:
+        assert lat.info("engine_next") == 3, "no register tiling across these slabs"
+        av2 = np.concatenate([lat.run(n) for n in steps])
+        assert lat.info("engine_last") == 3 and lat.info("resident_fallback") == 0
+        st2 = lat.read_state()
+        lat.set_option("engine", 1)              # ... and the streaming kernels carry on from that lattice
+        av3 = lat.run(4)
+        st3 = lat.read_state()
+        assert lat.info("engine_last") == 1
+    assert np.array_equal(st1.view(np.uint32), st2.view(np.uint32))
+    assert np.allclose(av1, av2, rtol=2e-6, atol=0)
+    with L.Lattice(p, ob, st1) as lat:
+        lat.set_option("time_block", 1)
+        av4 = lat.run(4)
+        st4 = lat.read_state()
+    assert np.array_equal(st3.view(np.uint32), st4.view(np.uint32))
+    assert np.allclose(av3, av4, rtol=2e-6, atol=0)
+
+
+def test_register_tiles_across_slabs_compiler_scheduled_loop_and_ieee_flavour(gpu):
+    """The other instantiations of lbm_regtile_slabs: regtile_async 0 (R = 4 and 2), kernel_variant 0 (IEEE division and root)."""
+    L = gpu
+    pf, of = deck_paths("1024x1024")
+    p = L.read_params(pf)
+    ob = L.read_obstacles(of, p)
+    for variant, async_, nslabs in ((3, 0, 4), (2, 1, 2), (2, 0, 8)):
+        with L.Lattice(p, ob) as lat:
+            lat.set_option("kernel_variant", variant)
+            lat.set_option("time_block", 1)
+            av1 = lat.run(19)
+            st1 = lat.read_state()
+        with L.Lattice(p, ob, nslabs=nslabs, devices=[0] * nslabs, exchange=L.EXCHANGE_P2P) as lat:
+            lat.set_option("kernel_variant", variant)
+            lat.set_option("regtile_async", async_)
+            av2 = lat.run(19)
+            assert lat.info("engine_last") == 3
+            st2 = lat.read_state()
+        assert np.array_equal(st1.view(np.uint32), st2.view(np.uint32)), (variant, async_, nslabs)
+        assert np.allclose(av1, av2, rtol=2e-6, atol=0)
+
+
+def test_register_tiles_across_slabs_that_cannot_finish_fall_back(gpu, monkeypatch):
+    """A tile of slab 0 never starts: its neighbours -- in this slab and in the slabs either side -- time out, every slab leaves
+    its source lattice untouched and the run is repeated with the halo-trading kernels."""
+    L = gpu
+    p, ob, cells = _random_case(L, 128, 128, 21)
+    with L.Lattice(p, ob, cells) as a:
+        a.set_option("time_block", 1)
+        av_a = a.run(9)
+        st_a = a.read_state()
+    monkeypatch.setenv("LBM_REGTILE_FAULT", "1")
+    with L.Lattice(p, ob, cells, nslabs=4, devices=[0] * 4, exchange=L.EXCHANGE_P2P) as b:
+        assert b.info("engine_next") == 3
+        t0 = time.perf_counter()
+        av_b = b.run(9)
+        waited = time.perf_counter() - t0
+        assert b.info("engine_last") == 1 and 0.5 < waited < 10.0 and b.info("resident_fallback") == 1
+        st_b = b.read_state()
+    assert np.array_equal(st_a.view(np.uint32), st_b.view(np.uint32))
+    assert np.allclose(av_a, av_b, rtol=2e-6, atol=0)
+
+
+def test_register_tiles_rank_context_ring_of_one(gpu, monkeypatch):
+    """The rank form (communicator, handle all-gather, the 'did anybody give up' double behind the sums in the closing
+    all-reduce) on a ring of one: the slab's neighbours are itself, as in the strong-scaling proxy."""
+    L = gpu
+    pf, of = deck_paths("1024x1024")
+    p0 = L.read_params(pf)
+    p = L.Param(1024, 128, p0.maxIters, p0.reynolds_dim, p0.density, p0.accel, p0.omega)
+    ob = L.read_obstacles(of, p0)[:128].copy()
+    with L.Lattice(p, ob) as lat:
+        lat.set_option("time_block", 1)
+        av1 = np.concatenate([lat.run(37), lat.run(4)])
+        st1 = lat.read_state()
+    monkeypatch.setenv("LBM_FORCE_EXCHANGE", "1")
+    with L.Lattice(p, ob, rank=0, nranks=1, device=0, unique_id=L.rccl_unique_id(), exchange=L.EXCHANGE_P2P) as lat:
+        assert lat.info("exchange") == L.EXCHANGE_P2P and lat.info("engine_next") == 3
+        av2 = np.concatenate([lat.run(37), lat.run(4)])
+        assert lat.info("engine_last") == 3
+        st2 = lat.read_state()
+    assert np.array_equal(st1.view(np.uint32), st2.view(np.uint32))
+    assert np.allclose(av1, av2, rtol=2e-6, atol=0)
+
+
+def _regtile_rank_worker(rank, nranks, shape, nsteps_list, conn, outdir):
+    import sys
+    for p_ in (ROOT, os.path.join(ROOT, "oracle")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    os.environ["LBM_REGTILE_SLABS_NO_AGREEMENT"] = "1"     # (no communicator between two processes on one GPU: see the test)
+    import advanced_hpc_lbm_amd as L
+    p, ob, cells = _random_case(L, shape[0], shape[1], 13)
+    lat = L.Lattice(p, ob, cells, rank=rank, nranks=nranks, device=0, unique_id=None, exchange=L.EXCHANGE_P2P)
+    conn.send(lat.p2p_handle())
+    lat.p2p_connect(conn.recv())
+    engine_next = int(lat.info("engine_next"))
+    av = np.concatenate([lat.run(n) for n in nsteps_list])
+    np.save(os.path.join(outdir, f"av_{rank}.npy"), av)
+    np.save(os.path.join(outdir, f"state_{rank}.npy"), lat.read_state())
+    conn.send(("done", engine_next, int(lat.info("engine_last"))))
+    conn.recv()          # keep the mail areas mapped until every rank has finished
+    lat.close()
+
+
+@pytest.mark.parametrize("nranks,shape", [(2, (256, 64)), (3, (128, 96))])
+def test_register_tiles_between_processes(gpu, tmp_path, nranks, shape):
+    """One process per slab (here sharing one GPU): a rank's tiles store their outgoing granules into the NEIGHBOURING
+    PROCESS's mail area, mapped through a hipIpc handle that travels in the halo block.  Two processes on one GPU cannot form a
+    RCCL communicator, so the agreement all-reduce that normally ends such a run is switched off for this test
+    (LBM_REGTILE_SLABS_NO_AGREEMENT) and the per-rank av_vels contributions are added here."""
+    import multiprocessing as mp
+    L = gpu
+    splits = [16, 11]
+    p, ob, cells = _random_case(L, shape[0], shape[1], 13)
+    with L.Lattice(p, ob, cells) as lat:
+        lat.set_option("time_block", 1)
+        av1 = np.concatenate([lat.run(n) for n in splits])
+        st1 = lat.read_state()
+    ctx = mp.get_context("spawn")
+    pipes = [ctx.Pipe() for _ in range(nranks)]
+    procs = [ctx.Process(target=_regtile_rank_worker, args=(r, nranks, shape, splits, pipes[r][1], str(tmp_path)))
+             for r in range(nranks)]
+    for pr in procs:
+        pr.start()
+    engines = []
+    try:
+        handles = []
+        for r in range(nranks):
+            assert pipes[r][0].poll(120), f"rank {r} did not come up"
+            handles.append(pipes[r][0].recv())
+        for r in range(nranks):
+            pipes[r][0].send(handles)
+        for r in range(nranks):
+            assert pipes[r][0].poll(120), f"rank {r} did not finish"
+            msg = pipes[r][0].recv()
+            assert msg[0] == "done"
+            engines.append(msg[1:])
+        for r in range(nranks):
+            pipes[r][0].send("bye")
+    finally:
+        for pr in procs:
+            pr.join(60)
+            if pr.is_alive():
+                pr.kill()
+    assert all(pr.exitcode == 0 for pr in procs)
+    av2 = sum(np.load(tmp_path / f"av_{r}.npy").astype(np.float64) for r in range(nranks))
+    st2 = np.concatenate([np.load(tmp_path / f"state_{r}.npy") for r in range(nranks)], axis=0)
+    assert np.array_equal(st1.view(np.uint32), st2.view(np.uint32))
+    assert np.allclose(av1, av2, rtol=2e-6, atol=0)
+    assert all(e == (3, 3) for e in engines), engines      # every rank tried, and ran, the register tiles
+
+
 KERNEL_SELECTION = {
     (128, 128, 1, "none"): (3, 2, 0, 0),
     (128, 256, 1, "none"): (3, 2, 0, 0),
@@ -1457,9 +1634,9 @@ KERNEL_SELECTION = {
     (48, 4096, 1, "none"): (1, 1, 0, 0),
     (64, 8, 1, "none"): (3, 1, 0, 0),
     (1024, 128, 1, "none"): (3, 2, 0, 0),
-    (1024, 1024, 2, "copy"): (1, 2, 0, 0),
-    (1024, 1024, 8, "copy"): (1, 2, 0, 0),
-    (1024, 1024, 8, "p2p"): (1, 2, 0, 0),
+    (1024, 1024, 2, "copy"): (3, 2, 0, 0),
+    (1024, 1024, 8, "copy"): (3, 2, 0, 0),
+    (1024, 1024, 8, "p2p"): (3, 2, 0, 0),
     (8192, 8192, 2, "p2p"): (1, 8, 1, 2),
     (8192, 8192, 4, "p2p"): (1, 8, 1, 2),
     (8192, 8192, 8, "p2p"): (1, 8, 1, 2),
@@ -1467,7 +1644,7 @@ KERNEL_SELECTION = {
     (4096, 4096, 4, "p2p"): (1, 8, 1, 1),
     (2048, 2048, 2, "copy"): (1, 4, 0, 0),
     (1000, 600, 3, "copy"): (1, 1, 0, 0),
-    (256, 256, 4, "p2p"): (1, 2, 0, 0),
+    (256, 256, 4, "p2p"): (3, 2, 0, 0),
     (6144, 6144, 1, "none"): (1, 8, 1, 2),
     (4096, 4096, 2, "p2p"): (1, 8, 1, 2),
     (8192, 1024, 1, "rccl"): (1, 8, 1, 1),

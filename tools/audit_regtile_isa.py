@@ -115,17 +115,18 @@ def main():
     total, allf, kernels = 0, [], 0
     i = 0
     while i < len(lines):
-        m = re.match(r"^(_ZN3lbm11lbm_regtileILi(\d+)ELi(\d+)EEEvNS_11RegTileArgsE):", lines[i])
+        m = re.match(r"^(_ZN3lbm(?:11lbm_regtile|17lbm_regtile_slabs)ILi(\d+)ELi(\d+)EEEv(?:NS_11RegTileArgsE|PKNS_11RegTileArgsE)):", lines[i])
         if m and (int(m.group(3)) & 4096) and int(m.group(2)) > 1:
             j = i
             while j < len(lines) and not lines[j].strip().startswith(".end_amdhsa_kernel"):
                 j += 1
             body = lines[i:j]
             scratch = [ln for ln in body if "private_segment_fixed_size" in ln]
-            n, f = audit_kernel(f"lbm_regtile<{m.group(2)}, {m.group(3)}>", body)
+            kname = ("lbm_regtile_slabs" if "slabs" in m.group(1) else "lbm_regtile") + f"<{m.group(2)}, {m.group(3)}>"
+            n, f = audit_kernel(kname, body)
             if scratch and not scratch[0].strip().endswith(" 0"):
-                f.append(f"lbm_regtile<{m.group(2)}, {m.group(3)}>: scratch in use: {scratch[0].strip()}")
-            print(f"lbm_regtile<{m.group(2)}, {m.group(3)}>: {n} asm loads audited, {len(f)} finding(s)")
+                f.append(f"{kname}: scratch in use: {scratch[0].strip()}")
+            print(f"{kname}: {n} asm loads audited, {len(f)} finding(s)")
             total += n
             allf += f
             kernels += 1
