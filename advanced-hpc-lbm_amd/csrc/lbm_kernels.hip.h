@@ -35,6 +35,18 @@ namespace lbm {
 
 constexpr int kBlock = 256;  // 4 waves of 64
 
+// The relaxation parameter and what the collision needs of it, worked out ONCE, on the host, in float (a GPU of this
+// generation has no scalar float unit: derived inside a kernel these wave-uniform numbers would sit in vector registers).
+// Every kernel's argument block carries one (`omega`; assigning a float converts), so every kernel collides with the same
+// three numbers.
+struct Relax {
+  float omega;                 // d2q9-bgk.c: params.omega
+  float omc;                   // 1 - omega
+  float w1;                    // omega x 1/9: the axis directions' weight; the rest direction's is 4 x, the diagonals' 1/4 x (exact)
+  Relax() = default;
+  __host__ __device__ Relax(float om) : omega(om), omc(1.f - om), w1(om * (1.f / 9.f)) {}
+};
+
 struct SweepArgs {
   const float* src;            // source lattice: plane k at src + k*plane
   float* dst;                  // destination lattice
@@ -49,7 +61,7 @@ struct SweepArgs {
   // "row nyl": planes 4,7,8 of the slab to the north (or own row 0 if alone)
   const float* north4; const float* north7; const float* north8;
   const uint8_t* blocked;      // nyl * pitch bytes, 1 = obstacle
-  float omega;
+  Relax omega;                 // params.omega and what the collision derives from it
   int accel_row;               // local row that receives the next step's accelerate, or -1
   float a1, a2;                // density*accel/9, density*accel/36
   float* partials;             // one float per block of this launch: sum of |u'|
@@ -124,30 +136,38 @@ template <bool FAST> __device__ __forceinline__ float root(float x) {
 
 // One cell: p[] holds the nine pulled values on entry and the nine values to
 // store on exit.  Returns the cell's contribution to the step's speed sum.
-// Arithmetic follows SURVEY.md Appendix A (= d2q9-bgk.c:982-1130) with
-// c_sq = 1/3 folded into the constants: 1/c_sq = 3, 1/(2 c_sq^2) = 4.5,
-// 1/(2 c_sq) = 1.5, and one reciprocal of the density shared by both
-// velocity components (the reference's own -Ofast build does the same).
-// Every multiply-add below is spelled out (fmaf) and contraction is switched off for the
-// function, so the sequence of float operations per cell is fixed by this text and not by
-// what the optimiser happens to fuse in a given instantiation: all kernels built from it
-// (1, 2 or 4 cells per thread, one or two steps per pass, any slab decomposition) produce
-// bit-identical lattices.
+// The arithmetic is SURVEY.md Appendix A (= d2q9-bgk.c:982-1130) with c_sq = 1/3 folded into the constants
+// (1/c_sq = 3, 1/(2 c_sq^2) = 4.5, 1/(2 c_sq) = 1.5), ARRANGED FOR THE INSTRUCTION COUNT -- every kernel of this library
+// that keeps more than one step on the chip is bound by the vector instructions of this function:
+//   * one reciprocal of the density for both velocity components (the reference's own -Ofast build does the same);
+//   * the three-population sums E, W, N, S serve the density AND the momenta (14 adds for what took 18);
+//   * relaxation folded into the equilibrium: t_k = (1 - omega) p_k + (omega w_k rho) (base + u_k (3 + 4.5 u_k)) -- one
+//     multiply-add behind the equilibrium instead of a subtraction and a multiply-add, the omega w_1 coming ready-made
+//     (Relax) and w_0 = 4 w_1, w_5..8 = w_1 / 4 being exact in binary.
+// 70 vector instructions per cell with the ten bounce-back selects (round 2's form: 83).  (Letting opposite directions share
+// base + 4.5 u_k^2 would take three more off, and cost the two-column lbm_wave 45 spilled registers: measured, not used.)
+// Mathematically the same numbers as before; the rounding differs in the last bits (tests/test_gpu_parity.py holds one step
+// to 4e-6 per element of the reference's known answers, as before).  Every multiply-add is spelled out (fmaf) and
+// contraction is switched off for the function, so the sequence of float operations per cell is fixed by this text and not
+// by what the optimiser happens to fuse in a given instantiation: all kernels built from it (1, 2 or 4 cells per thread,
+// any number of steps per pass, any decomposition) produce bit-identical lattices.
 template <bool FAST, bool SPARSE = false, bool STORED = false>
-__device__ __forceinline__ float collide_cell(float (&p)[9], bool is_blocked, float omega) {
+__device__ __forceinline__ float collide_cell(float (&p)[9], bool is_blocked, const Relax& om) {
 #pragma clang fp contract(off)
-  const float w0 = 4.f / 9.f, w1 = 1.f / 9.f, w2 = 1.f / 36.f;
-  float rho = p[0];
-  rho += p[1]; rho += p[2]; rho += p[3]; rho += p[4];
-  rho += p[5]; rho += p[6]; rho += p[7]; rho += p[8];
+  const float E = (p[1] + p[5]) + p[8];
+  const float W = (p[3] + p[6]) + p[7];
+  const float N = (p[2] + p[5]) + p[6];
+  const float S = (p[4] + p[7]) + p[8];
+  float rho = p[0] + E;
+  rho += W; rho += p[2]; rho += p[4];
   const float inv = recip<FAST>(rho);
-  const float ux = (p[1] + p[5] + p[8] - (p[3] + p[6] + p[7])) * inv;
-  const float uy = (p[2] + p[5] + p[6] - (p[4] + p[7] + p[8])) * inv;
+  const float ux = (E - W) * inv;
+  const float uy = (N - S) * inv;
   const float usq = __builtin_fmaf(ux, ux, uy * uy);
   const float base = __builtin_fmaf(-1.5f, usq, 1.f);          // 1 - u_sq / (2 c_sq)
-  const float r0 = w0 * rho, r1 = w1 * rho, r2 = w2 * rho;
+  const float r1 = om.w1 * rho, r0 = 4.f * r1, r2 = 0.25f * r1;   // omega w_k rho
   const float upp = ux + uy, upm = ux - uy;
-  // d_k = w_k rho (1 + u_k/c_sq + u_k^2/(2 c_sq^2) - u_sq/(2 c_sq)) = w_k rho (base + u_k (3 + 4.5 u_k))
+  // omega d_k = omega w_k rho (1 + u_k/c_sq + u_k^2/(2 c_sq^2) - u_sq/(2 c_sq)) = (omega w_k rho) (base + u_k (3 + 4.5 u_k))
   float d[9];
   d[0] = r0 * base;
   d[1] = r1 * __builtin_fmaf(ux, __builtin_fmaf(4.5f, ux, 3.f), base);
@@ -160,13 +180,12 @@ __device__ __forceinline__ float collide_cell(float (&p)[9], bool is_blocked, fl
   d[8] = r2 * __builtin_fmaf(upm, __builtin_fmaf(4.5f, upm, 3.f), base);
   float t[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) t[k] = __builtin_fmaf(omega, d[k] - p[k], p[k]);   // p + omega (d - p)
+  for (int k = 0; k < 9; ++k) t[k] = __builtin_fmaf(om.omc, p[k], d[k]);   // (1 - omega) p + omega d
   // The cell's speed for the step's average (d2q9-bgk.c:1783-1811 takes it from the post-collision populations).
   // BGK relaxation conserves the cell's mass and momentum -- sum t_k = rho and sum t_k c_k = rho u, the equilibrium
   // having been built from exactly these -- so the post-collision velocity IS (ux, uy), up to the rounding of the
   // float sums (a few 1e-9 absolute per cell, random in sign: parts in 1e8 of a step's average, against the 1 % of
-  // the reference's checker and the 2e-6 the tests hold it to).  Recomputing it from t[] cost 24 of the ~110
-  // instructions of this function, in kernels that are bound by exactly those (lbm_regtile, lbm_wave).
+  // the reference's checker and the 2e-6 the tests hold it to).  Recomputing it from t[] cost 24 instructions.
   // STORED: the reference's form -- density and velocity re-summed from the values about to be stored.
   float speed;
   if constexpr (STORED) {
@@ -207,30 +226,34 @@ __device__ __forceinline__ float collide_cell(float (&p)[9], bool is_blocked, fl
 // DIFFERENT cells, so that a wave has C independent chains to issue from (lbm_wave with two columns per lane runs two
 // waves per SIMD: there it is instruction-level parallelism, not other waves, that has to keep the SIMD's issue slots full).
 template <bool FAST, int C>
-__device__ __forceinline__ void collide_cells(float (&p)[C][9], const bool (&is_blocked)[C], float omega, float (&speed)[C]) {
+__device__ __forceinline__ void collide_cells(float (&p)[C][9], const bool (&is_blocked)[C], const Relax& om, float (&speed)[C]) {
 #pragma clang fp contract(off)
-  const float w0 = 4.f / 9.f, w1 = 1.f / 9.f, w2 = 1.f / 36.f;
-  float rho[C], inv[C], ux[C], uy[C], usq[C], base[C], r0[C], r1[C], r2[C], upp[C], upm[C], d[C][9], t[C][9];
+  float E[C], W[C], N[C], S[C], rho[C], inv[C], ux[C], uy[C], usq[C], base[C], r0[C], r1[C], r2[C], upp[C], upm[C], d[C][9], t[C][9];
 #define LBM_EACH for (int c = 0; c < C; ++c)
 #pragma unroll
-  LBM_EACH rho[c] = p[c][0];
+  LBM_EACH { E[c] = (p[c][1] + p[c][5]) + p[c][8]; W[c] = (p[c][3] + p[c][6]) + p[c][7]; }
 #pragma unroll
-  for (int k = 1; k < 9; ++k) {
+  LBM_EACH { N[c] = (p[c][2] + p[c][5]) + p[c][6]; S[c] = (p[c][4] + p[c][7]) + p[c][8]; }
 #pragma unroll
-    LBM_EACH rho[c] += p[c][k];
-  }
+  LBM_EACH rho[c] = p[c][0] + E[c];
+#pragma unroll
+  LBM_EACH rho[c] += W[c];
+#pragma unroll
+  LBM_EACH rho[c] += p[c][2];
+#pragma unroll
+  LBM_EACH rho[c] += p[c][4];
 #pragma unroll
   LBM_EACH inv[c] = recip<FAST>(rho[c]);
 #pragma unroll
-  LBM_EACH ux[c] = (p[c][1] + p[c][5] + p[c][8] - (p[c][3] + p[c][6] + p[c][7])) * inv[c];
+  LBM_EACH ux[c] = (E[c] - W[c]) * inv[c];
 #pragma unroll
-  LBM_EACH uy[c] = (p[c][2] + p[c][5] + p[c][6] - (p[c][4] + p[c][7] + p[c][8])) * inv[c];
+  LBM_EACH uy[c] = (N[c] - S[c]) * inv[c];
 #pragma unroll
   LBM_EACH usq[c] = __builtin_fmaf(ux[c], ux[c], uy[c] * uy[c]);
 #pragma unroll
   LBM_EACH base[c] = __builtin_fmaf(-1.5f, usq[c], 1.f);
 #pragma unroll
-  LBM_EACH { r0[c] = w0 * rho[c]; r1[c] = w1 * rho[c]; r2[c] = w2 * rho[c]; upp[c] = ux[c] + uy[c]; upm[c] = ux[c] - uy[c]; }
+  LBM_EACH { r1[c] = om.w1 * rho[c]; r0[c] = 4.f * r1[c]; r2[c] = 0.25f * r1[c]; upp[c] = ux[c] + uy[c]; upm[c] = ux[c] - uy[c]; }
 #pragma unroll
   LBM_EACH d[c][0] = r0[c] * base[c];
 #pragma unroll
@@ -252,7 +275,7 @@ __device__ __forceinline__ void collide_cells(float (&p)[C][9], const bool (&is_
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
 #pragma unroll
-    LBM_EACH t[c][k] = __builtin_fmaf(omega, d[c][k] - p[c][k], p[c][k]);
+    LBM_EACH t[c][k] = __builtin_fmaf(om.omc, p[c][k], d[c][k]);
   }
 #pragma unroll
   LBM_EACH speed[c] = is_blocked[c] ? 0.f : root<FAST>(usq[c]);
@@ -583,7 +606,7 @@ struct Sweep2Args {
   long plane;
   int pitch, nx, ny;           // ny = rows of this slab (the whole lattice if alone)
   const uint8_t* blocked;
-  float omega;
+  Relax omega;                 // params.omega and what the collision derives from it
   int accel_row;               // local row of global row ny-2, or kNoRow
   int accel_out;               // apply the accelerate phase to the outputs (0 on the last pair)
   float a1, a2;

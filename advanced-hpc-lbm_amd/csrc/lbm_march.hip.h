@@ -39,7 +39,7 @@ struct MarchArgs {
   long plane;
   int pitch, nx, ny;
   const uint8_t* blocked;
-  float omega;
+  Relax omega;
   int accel_row;               // global row ny-2
   int accel_out;               // apply the accelerate phase of step t+K+1 to the outputs
   float a1, a2;

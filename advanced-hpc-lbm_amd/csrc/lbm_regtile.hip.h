@@ -79,7 +79,7 @@ __global__ void lbm_abort_to_sum(const uint32_t* abort_word, double* out) {
 struct RegTileArgs {
   const float* src; float* dst; long plane; int pitch, nx, ny;
   const uint8_t* blocked;
-  float omega; int accel_row; float a1, a2;
+  Relax omega; int accel_row; float a1, a2;
   int ty;                      // rows per tile = waves per block x R
   int ntx, nty;                // tiles per lattice row (nx / 64) / column (ny / ty); gridDim.x = ntx * nty
   int nsteps;

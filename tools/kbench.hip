@@ -87,7 +87,7 @@ struct Sweep3Args {
   long plane;
   int pitch, nx, ny;
   const uint8_t* blocked;
-  float omega;
+  lbm::Relax omega;
   int accel_row;               // row ny-2, or kNoRow
   int accel_out;               // accelerate the outputs too (0 when the run ends with this launch)
   float a1, a2;
