@@ -765,9 +765,10 @@ double slab_wave_efficiency(const lbm_ctx* c, int ny_rows, int h, int K = 8, int
 int march_rows_for(const lbm_ctx* c, int ny_rows);
 int wave_slots(const lbm_ctx* c, int K);
 
-// lbm_wave<8>: one or two columns per lane?  Each form is priced by what it does with a full chip -- 371 GLUPS with one
-// column (three waves per SIMD, 48 of 64 lanes delivered), 411 with two (two waves per SIMD, 112 of 128 delivered, the two
-// cells of a lane issued statement by statement) -- times the useful share of its wave-slot time with its best chunk
+// lbm_wave<8>: one or two columns per lane?  Each form is priced by what it does with a full chip -- 394 GLUPS with one
+// column (three waves per SIMD, 48 of 64 lanes delivered), 456 with two (two waves per SIMD, 112 of 128 delivered, the two
+// cells of a lane issued statement by statement; both figures rose by 6 / 11 % with the 70-instruction collision, the
+// measurements quoted below are from before it) -- times the useful share of its wave-slot time with its best chunk
 // height on `rows` rows.  Measured in one call (profiles/r03_wave_two_columns.log): 8192^2 348 against 320 GLUPS (149-row
 // chunks: 4070 waves for 2 x 2048 slots), 6144^2 324 against 314, 4096^2 219 against 274 (too few waves for two rounds);
 // 8192-wide slabs of N = 2 / 4 / 8: 113 / 62.8 / 35.5 us per step against 119 / 66.7 / 37.4.  What the two-column form wants
@@ -784,7 +785,7 @@ double wave_pick_cols(lbm_ctx* c, int rows, int* rows_per_chunk) {
     const int was = c->wave_cols;
     c->wave_cols = cols;
     const int h = slab_wave_rows(c, rows, 8);
-    const double rate = (cols == 2 ? 411.0 : 371.0) * slab_wave_efficiency(c, rows, h, 8);
+    const double rate = (cols == 2 ? 456.0 : 394.0) * slab_wave_efficiency(c, rows, h, 8);
     c->wave_cols = was;
     if (rate > best) { best = rate; best_c = cols; best_h = h; }
   }
@@ -885,7 +886,9 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
           (double)c->p.ny * c->slabs[0].pitch * 4.0 < 4.0e9) {
         int h = 0;
         const int cols_was = c->wave_cols;
-        if (wave_pick_cols(c, c->p.ny, &h) >= 300.0 * march_efficiency(c, march_pick_rows(c))) {
+        // (x 0.88: for a single short round the wave-slot model is about a tenth too pessimistic -- 2048^2 predicted 205, measured
+        // 247, lbm_march 231; 2560^2 254 / 277-281 / 254 -- profiles/r03_default_kernel_by_size.log)
+        if (wave_pick_cols(c, c->p.ny, &h) >= 0.88 * 300.0 * march_efficiency(c, march_pick_rows(c))) {
           c->time_block = 8; c->march_kernel = 1;
           if (c->wave_rows <= 0) c->wave_rows = h;
         } else c->wave_cols = cols_was;
@@ -1905,19 +1908,34 @@ void regtile_set(lbm_ctx* c, int ty, int r) {
   c->tplan.ty = ty; c->tplan.r = r; c->tplan.nw = ty / r; c->tplan.ntx = c->p.nx / 64; c->tplan.nty = c->p.ny / ty;
   c->tplan.bpc = 0;          // (the residency of this tiling has not been asked yet)
 }
-// Default tiling.  A step is bounded by the hand-off with the neighbouring tiles (about 1.6 us) plus the serial
-// work of one wave, so: as few rows per wave as the lattice allows (1, then 2, then 4), and tiles of several
-// waves (they trade rows through LDS, not through mailboxes) on at most half the CUs where that is possible.
-// Measured, us per step: 128^2 1.63 (2 waves x 1 row; 256 one-wave tiles: 2.09), 256^2 2.02 (4 x 1), 1024^2 5.05
-// (16 x 4, the only shape that fits one block per CU; two 8-wave blocks per CU: 4.95).
+// Default tiling (of a lattice alone and of equal slabs alike; `per_dev` = slabs sharing a device, `rows` = rows per slab).
+// Measured with the mailboxes in uncached memory (profiles/r03_regtile_tilings.log), us per step: the SHORTEST tiles that
+// still fit one per CU win -- 1024x512: 32 rows 2.26, 64 rows 2.94; 1024x256: 16 rows 1.94, 32 rows 2.20; 1024x128: 8 rows
+// 1.58, 16 rows 1.87; 256x256: 4 rows 1.34, 8 rows 1.38 -- but not one-row tiles (128x128: 2 rows 1.26, 1 row 1.31); and
+// within a tile height, as few rows per wave as leave at most EIGHT waves (they meet at a barrier every step; 1024x256,
+// 16-row tiles: 16 x 1 rows 2.00, 8 x 2 1.94, 4 x 4 1.98; 1024x128, 8-row tiles: 8 x 1 1.58, 4 x 2 1.76, 2 x 4 1.93),
+// sixteen where the lattice leaves no choice (1024x1024: 16 waves x 4 rows, 2.94).
+bool regtile_default_tiling(const lbm_ctx* c, int rows, int per_dev, int* ty_out, int* r_out) {
+  if (c->p.nx % 64 != 0 || rows < 1) return false;
+  const long ntx = c->p.nx / 64;
+  for (int ty = (rows >= 2 ? 2 : 1); ty <= std::min(rows, 64); ++ty) {
+    if (rows % ty != 0 || (long)per_dev * ntx * (rows / ty) > (long)c->ncu) continue;
+    for (int waves : {8, 16})
+      for (int r : {1, 2, 4}) {
+        if (ty % r != 0 || ty / r > waves) continue;
+        if ((160 * 1024) / lbm::regtile_lds_bytes(ty / r, r) < 1) continue;
+        *ty_out = ty; *r_out = r;
+        return true;
+      }
+  }
+  return false;
+}
 bool plan_regtile(lbm_ctx* c) {
   c->tplan.ty = 0;
-  const long ntx = c->p.nx / 64;
-  for (long limit : {(long)c->ncu / 2, (long)c->ncu})
-    for (int r : {1, 2, 4})
-      for (int ty = r; ty <= std::min(c->p.ny, 16 * r); ty += r)
-        if (regtile_ok(c, ty, r) && ntx * (c->p.ny / ty) <= limit) { regtile_set(c, ty, r); return true; }
-  return false;
+  int ty = 0, r = 0;
+  if (!regtile_default_tiling(c, c->p.ny, 1, &ty, &r) || !regtile_ok(c, ty, r)) return false;
+  regtile_set(c, ty, r);
+  return true;
 }
 
 // The instantiation of lbm_regtile for a tiling and flavour (dbg: the LBM_RESIDENT_DEBUG timing experiments, R = 4 only).
@@ -2129,19 +2147,16 @@ bool plan_regtile_slabs(lbm_ctx* c) {
     for (auto& b : c->slabs) n += (b.dev == a.dev) ? 1 : 0;
     per_dev = std::max(per_dev, n);
   }
-  const long ntx = c->p.nx / 64;
-  for (long limit : {(long)c->ncu / 2, (long)c->ncu})
-    for (int r : {1, 2, 4})
-      for (int ty = r; ty <= std::min(nyl, 16 * r); ty += r) {
-        if (nyl % ty != 0) continue;
-        const int nw = ty / r;
-        const int lds_per_cu = (160 * 1024) / lbm::regtile_lds_bytes(nw, r);
-        if (lds_per_cu < 1) continue;
-        if (per_dev * ntx * (nyl / ty) > limit) continue;
-        c->splan.ty = ty; c->splan.r = r; c->splan.nw = nw; c->splan.ntx = (int)ntx; c->splan.nty = nyl / ty; c->splan.bpc = 0;
-        return true;
-      }
-  return false;
+  // (development: LBM_REGTILE_SLAB_TILING = rows per tile x 10 + rows per wave, as the `regtile` option of a lone lattice)
+  const int forced = getenv("LBM_REGTILE_SLAB_TILING") ? atoi(getenv("LBM_REGTILE_SLAB_TILING")) : 0;
+  int ty = 0, r = 0;
+  if (forced > 0) {
+    ty = forced / 10; r = forced % 10;
+    if (!(r == 1 || r == 2 || r == 4) || ty < r || ty % r != 0 || ty / r > 16 || nyl % ty != 0 ||
+        (long)per_dev * (c->p.nx / 64) * (nyl / ty) > (long)c->ncu) return false;
+  } else if (!regtile_default_tiling(c, nyl, per_dev, &ty, &r)) return false;
+  c->splan.ty = ty; c->splan.r = r; c->splan.nw = ty / r; c->splan.ntx = c->p.nx / 64; c->splan.nty = nyl / ty; c->splan.bpc = 0;
+  return true;
 }
 
 typedef void (*regtile_slabs_fn)(const lbm::RegTileArgs*);
