@@ -10,6 +10,7 @@ import advanced_hpc_lbm_amd as L
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
 t0, n, bad = time.time(), 0, 0
+n_reg, n_reg_slabs = 0, 0       # configurations that ran lbm_regtile: alone / across slabs
 w = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4)
 while time.time() - t0 < budget:
     nx = int(rng.choice([64, 128, 192, 256, 65, 100, 130, 66, 320, 1000]))
@@ -26,15 +27,19 @@ while time.time() - t0 < budget:
         if ny // ns >= 2:
             configs += [dict(nslabs=ns, exchange=L.EXCHANGE_COPY), dict(nslabs=ns, exchange=L.EXCHANGE_P2P)]
     for cfg in configs:
-        for threads in (256, 512, 1024):
+        for threads in (None, 256, 512, 1024):       # None: the default engine (lbm_regtile, alone or across slabs, where a size tiles)
             ns = cfg["nslabs"]
             kw = dict(cfg); kw["devices"] = [0] * ns
             with L.Lattice(p, ob, c0, **kw) as lat:
-                lat.set_option("t2_threads", threads)
+                if threads is not None:
+                    lat.set_option("t2_threads", threads)
                 av = np.concatenate([lat.run(k) for k in splits]); st = lat.read_state()
                 tb = int(lat.info("time_block_active"))
+                if int(lat.info("engine_last")) == 3:
+                    n_reg += ns == 1
+                    n_reg_slabs += ns > 1
             n += 1
             if not np.array_equal(st.view(np.uint32), ref.view(np.uint32)) or not np.allclose(av, av_ref, rtol=5e-6, atol=0):
                 bad += 1
                 print("MISMATCH", nx, ny, cfg, threads, splits, "tb", tb, "max diff", float(np.abs(st - ref).max()), flush=True)
-print(f"fuzz: {n} configurations, {bad} mismatches, {time.time() - t0:.0f} s")
+print(f"fuzz: {n} configurations ({n_reg} through lbm_regtile alone, {n_reg_slabs} through register tiles across slabs), {bad} mismatches, {time.time() - t0:.0f} s")
