@@ -1172,12 +1172,18 @@ extern "C" int lbm_create_rank_ex(const lbm_param* params, const int* obstacles,
       if (!rc) (void)hipMemcpy(all.data(), d_buf, (size_t)nranks * hb, hipMemcpyDeviceToHost);
     }
     if (!rc && !p2p_rc) p2p_rc = (nranks > 1) ? p2p_connect_ipc(c, all.data(), nranks) : p2p_connect_local(c);
-    if (!rc) {  // agreement: sum of failures over all ranks
-      double fails = p2p_rc ? 1.0 : 0.0, *d_f = (double*)d_buf;
-      (void)hipMemcpy(d_f, &fails, sizeof(double), hipMemcpyHostToDevice);
-      int r = rccl::AllReduce(d_f, d_f, 1, rccl::kFloat64, rccl::kSum, s.comm, s.sc);
+    if (!rc) {  // agreement: sum of failures over all ranks -- [0] the halo blocks, [1] the mail areas of the register tiles
+      // (a rank whose mail area could not be allocated or mapped must not be the only one to know: the others would launch
+      // tiles that wait for its mail)
+      bool tiles_ok = c->splan.ty > 0;
+      if (tiles_ok && nranks > 1) for (int side = 0; side < 2; ++side) tiles_ok = tiles_ok && s.tmail_nb[side] != nullptr;
+      double both[2] = {p2p_rc ? 1.0 : 0.0, tiles_ok ? 0.0 : 1.0}, *d_f = (double*)d_buf;
+      (void)hipMemcpy(d_f, both, sizeof(both), hipMemcpyHostToDevice);
+      int r = rccl::AllReduce(d_f, d_f, 2, rccl::kFloat64, rccl::kSum, s.comm, s.sc);
       if (r != 0 || hipStreamSynchronize(s.sc) != hipSuccess) rc = fail(LBM_ERCCL, "peer-to-peer agreement failed");
-      else (void)hipMemcpy(&fails, d_f, sizeof(double), hipMemcpyDeviceToHost);
+      else (void)hipMemcpy(both, d_f, sizeof(both), hipMemcpyDeviceToHost);
+      const double fails = both[0];
+      if (!rc && both[1] > 0.0) c->splan.ty = 0;       // somebody has no register tiling: nobody uses it
       if (!rc && fails > 0.0) {
         // somebody could not map a neighbour: everyone trades halos by RCCL instead
         if (getenv("LBM_VERBOSE")) fprintf(stderr, "lbm: peer-to-peer halos unavailable (%s); using RCCL\n", p2p_rc ? g_err : "another rank failed");
