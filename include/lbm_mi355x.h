@@ -179,7 +179,14 @@ int lbm_destroy(lbm_ctx* ctx);
 int lbm_timestep(const lbm_param* params, float* cells, float* tmp_cells,
                  const int* obstacles, float* av_vel);
 
-/* Tuning / introspection (never needed for correctness). */
+/* Tuning / introspection (never needed for correctness; the table of keys is INTEGRATION.md section 3).
+ * Options: "engine" (0 auto, 1 streaming kernels, 3 register tiles -- alone or across slabs -- or fail), "time_block"
+ * (1, 2, 4, 6, 8 steps per pass), "march_kernel", "march_rows", "wave_rows", "wave_cols" (1, 2), "regtile" (tiling),
+ * "regtile_async" (0, 1), "kernel_variant" (bits: 1 fast rcp / sqrt, 2 / 4 nontemporal stores / loads, 8 the reference's
+ * form of the speed sum, d2q9-bgk.c:1783-1811, 256 one-step kernel only), "vector_width", "t2_threads".
+ * Info: "engine_last", "engine_next", "resident_fallback", "time_block_active", "march_kernel", "wave_rows",
+ * "wave_cols_active", "wave_out_cols", "regtile", "regtile_blocks_per_cu", "exchange", "compute_units", "fluid_cells",
+ * "pitch", "hbm_bytes". */
 int lbm_set_option(lbm_ctx* ctx, const char* key, long value);  /* e.g. "kernel_variant" */
 int lbm_get_info(const lbm_ctx* ctx, const char* key, double* value);
 
