@@ -39,7 +39,7 @@ ABI_SYMBOLS = (
     "lbm_create_rank_ex", "lbm_p2p_handle", "lbm_p2p_connect",
     "lbm_slab_rows", "lbm_num_slabs", "lbm_run", "lbm_last_run_ms", "lbm_read_state",
     "lbm_av_velocity", "lbm_reynolds", "lbm_total_density", "lbm_final_state", "lbm_destroy",
-    "lbm_timestep", "lbm_set_option", "lbm_get_info",
+    "lbm_timestep", "lbm_set_option", "lbm_get_info", "lbm_plan_tiles",
 )
 
 
@@ -107,6 +107,13 @@ def load_library():
 def _check(rc: int):
     if rc != 0:
         raise LbmError(f"[lbm error {rc}] {load_library().lbm_last_error().decode()}")
+
+
+def plan_tiles(nx: int, rows: int, slabs_per_device: int = 1, compute_units: int = 256):
+    """(rows per tile, rows per wavefront) of lbm_regtile's default tiling, or None where the lattice does not tile."""
+    ty, r = C.c_int(0), C.c_int(0)
+    rc = load_library().lbm_plan_tiles(nx, rows, slabs_per_device, compute_units, C.byref(ty), C.byref(r))
+    return (ty.value, r.value) if rc == 0 else None
 
 
 def device_count() -> int:

@@ -751,6 +751,7 @@ int ensure_sums(Slab& s, int nsteps) {
 
 bool plan_regtile(lbm_ctx* c);    // resident engine, below
 bool plan_regtile_slabs(lbm_ctx* c);
+bool regtile_tiling_rule(int nx, int rows, int per_dev, int ncu, int* ty_out, int* r_out);
 struct Slab;
 int regtile_slab_mail_alloc(lbm_ctx* c, Slab& s);
 size_t regtile_slab_mail_bytes(const lbm_ctx* c);
@@ -901,6 +902,17 @@ int finish_create(lbm_ctx* c, const int* obstacles, const float* cells) {
 }  // namespace
 
 // ----------------------------------------------------------------- C ABI
+// The tiling lbm_regtile would use: host arithmetic only (no device is touched), so that the rule can be tested where there
+// is no GPU (tests/test_abi.py).
+extern "C" int lbm_plan_tiles(int nx, int rows, int slabs_per_device, int compute_units, int* tile_rows, int* rows_per_wave) {
+  if (!tile_rows || !rows_per_wave) return fail(LBM_EINVAL, "NULL argument");
+  int ty = 0, r = 0;
+  if (!regtile_tiling_rule(nx, rows, slabs_per_device, compute_units, &ty, &r))
+    return fail(LBM_EINVAL, "no register tiling: %d columns x %d rows, %d slab(s) per device, %d compute units", nx, rows, slabs_per_device, compute_units);
+  *tile_rows = ty; *rows_per_wave = r;
+  return LBM_OK;
+}
+
 extern "C" int lbm_device_count(int* count) {
   if (!count) return fail(LBM_EINVAL, "count is NULL");
   int n = 0;
@@ -1921,11 +1933,11 @@ void regtile_set(lbm_ctx* c, int ty, int r) {
 // within a tile height, as few rows per wave as leave at most EIGHT waves (they meet at a barrier every step; 1024x256,
 // 16-row tiles: 16 x 1 rows 2.00, 8 x 2 1.94, 4 x 4 1.98; 1024x128, 8-row tiles: 8 x 1 1.58, 4 x 2 1.76, 2 x 4 1.93),
 // sixteen where the lattice leaves no choice (1024x1024: 16 waves x 4 rows, 2.94).
-bool regtile_default_tiling(const lbm_ctx* c, int rows, int per_dev, int* ty_out, int* r_out) {
-  if (c->p.nx % 64 != 0 || rows < 1) return false;
-  const long ntx = c->p.nx / 64;
+bool regtile_tiling_rule(int nx, int rows, int per_dev, int ncu, int* ty_out, int* r_out) {
+  if (nx < 64 || nx % 64 != 0 || rows < 1 || per_dev < 1 || ncu < 1) return false;
+  const long ntx = nx / 64;
   for (int ty = (rows >= 2 ? 2 : 1); ty <= std::min(rows, 64); ++ty) {
-    if (rows % ty != 0 || (long)per_dev * ntx * (rows / ty) > (long)c->ncu) continue;
+    if (rows % ty != 0 || (long)per_dev * ntx * (rows / ty) > (long)ncu) continue;
     for (int waves : {8, 16})
       for (int r : {1, 2, 4}) {
         if (ty % r != 0 || ty / r > waves) continue;
@@ -1935,6 +1947,9 @@ bool regtile_default_tiling(const lbm_ctx* c, int rows, int per_dev, int* ty_out
       }
   }
   return false;
+}
+bool regtile_default_tiling(const lbm_ctx* c, int rows, int per_dev, int* ty_out, int* r_out) {
+  return regtile_tiling_rule(c->p.nx, rows, per_dev, c->ncu, ty_out, r_out);
 }
 bool plan_regtile(lbm_ctx* c) {
   c->tplan.ty = 0;

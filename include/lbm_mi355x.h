@@ -179,6 +179,14 @@ int lbm_destroy(lbm_ctx* ctx);
 int lbm_timestep(const lbm_param* params, float* cells, float* tmp_cells,
                  const int* obstacles, float* av_vel);
 
+/*
+ * The tiling the register-resident engine (lbm_regtile: the whole lbm_run in one launch, replacing the loop of
+ * d2q9-bgk.c:180-201) would give a lattice -- or each of several equal slabs -- of nx columns x rows rows on a device
+ * with `compute_units` CUs that holds `slabs_per_device` such slabs: 64-column tiles of *tile_rows rows, one per CU,
+ * *rows_per_wave rows per wavefront.  Host arithmetic only (no device needed).  LBM_EINVAL: it does not tile.
+ */
+int lbm_plan_tiles(int nx, int rows, int slabs_per_device, int compute_units, int* tile_rows, int* rows_per_wave);
+
 /* Tuning / introspection (never needed for correctness; the table of keys is INTEGRATION.md section 3).
  * Options: "engine" (0 auto, 1 streaming kernels, 3 register tiles -- alone or across slabs -- or fail), "time_block"
  * (1, 2, 4, 6, 8 steps per pass), "march_kernel", "march_rows", "wave_rows", "wave_cols" (1, 2), "regtile" (tiling),

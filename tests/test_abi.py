@@ -79,3 +79,21 @@ def test_hand_issued_mail_loads_of_the_register_tile_kernel_are_left_alone_by_th
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_regtile_isa.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 finding(s)" in r.stdout and "asm loads audited" in r.stdout
+
+
+def test_register_tiling_rule(L):
+    """lbm_plan_tiles (host arithmetic, no GPU): the default tiling of lbm_regtile as measured on MI355X
+    (profiles/r03_regtile_tilings.log) -- the shortest tiles that fit one per CU, but not one-row tiles; at most eight
+    waves per tile where the lattice allows it, sixteen where it does not; slabs sharing a device share its CUs."""
+    assert L.plan_tiles(1024, 1024) == (64, 4)          # the shipped deck: 256 tiles of 16 waves x 4 rows
+    assert L.plan_tiles(1024, 512) == (32, 4)           # one rank's slab at N = 2 / 4 / 8
+    assert L.plan_tiles(1024, 256) == (16, 2)
+    assert L.plan_tiles(1024, 128) == (8, 1)
+    assert L.plan_tiles(256, 256) == (4, 1) and L.plan_tiles(128, 128) == (2, 1) and L.plan_tiles(128, 256) == (2, 1)
+    assert L.plan_tiles(64, 8) == (2, 1) and L.plan_tiles(64, 1) == (1, 1)
+    assert L.plan_tiles(1024, 128, slabs_per_device=8) == (64, 4)     # eight slabs on ONE device: the undivided lattice's tiles
+    assert L.plan_tiles(1024, 256, slabs_per_device=2) == (32, 4)
+    assert L.plan_tiles(1000, 1000) is None and L.plan_tiles(48, 64) is None      # width no multiple of 64
+    assert L.plan_tiles(2048, 2048) is None and L.plan_tiles(1024, 2048) is None  # more cells than the register file takes
+    assert L.plan_tiles(1024, 1024, compute_units=128) is None
+    assert L.plan_tiles(1024, 1000) is None             # 1000 rows: no tile height up to 64 divides them into <= 256 tiles ... (8 x 125)
