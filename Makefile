@@ -29,7 +29,13 @@ $(LIB): $(PKG)/csrc/lbm_api.hip $(PKG)/csrc/lbm_kernels.hip.h $(PKG)/csrc/lbm_ex
 $(EXE): $(PKG)/host/d2q9-bgk.c $(LIB) include/lbm_mi355x.h
 	$(CC) $(CFLAGS) -Iinclude $< -o $@ -L$(PKG) -llbm_mi355x -Wl,-rpath,'$$ORIGIN/$(PKG)' -Wl,-rpath,/opt/rocm/lib
 
-tools: tools/kbench tools/layout_bench tools/exact_math_check tools/oob_store_order
+tools: tools/kbench tools/layout_bench tools/exact_math_check tools/oob_store_order tools/valu_chain tools/valu_forms
+
+tools/valu_chain: tools/valu_chain.hip
+	$(HIPCC) -O3 --offload-arch=gfx950 -fno-slp-vectorize $< -o $@
+
+tools/valu_forms: tools/valu_forms.hip
+	$(HIPCC) -O3 --offload-arch=gfx950 -fno-slp-vectorize $< -o $@
 
 tools/oob_store_order: tools/oob_store_order.hip
 	$(HIPCC) -O2 --offload-arch=gfx950 -Wno-unused-value $< -o $@
@@ -52,4 +58,4 @@ check:
 .PHONY: all lib tools oracle check clean
 
 clean:
-	rm -f $(EXE) $(LIB) tools/kbench tools/layout_bench tools/exact_math_check tools/oob_store_order
+	rm -f $(EXE) $(LIB) tools/kbench tools/layout_bench tools/exact_math_check tools/oob_store_order tools/valu_chain tools/valu_forms
