@@ -34,6 +34,17 @@ __global__ __launch_bounds__(1024) void forms(float* out, int iters, float sa, f
     if constexpr (FORM == 14) { STEP("v_fma_f32 %0, %0, %4, -%5\n v_fma_f32 %1, -%1, %4, %5\n v_fma_f32 %2, %2, %4, -%5\n v_fma_f32 %3, -%3, %4, %5", "v"(va), "v"(vb)) }
     if constexpr (FORM == 15) { STEP("v_sub_f32 %0, %0, %4\n v_sub_f32 %1, %1, %4\n v_subrev_f32 %2, %4, %2\n v_sub_f32 %3, %3, %4", "v"(va)) }
   }
+  if constexpr (FORM >= 16) {           // packed forms: two floats per 64-bit register pair, four chains of pairs
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 y0 = {x0, x1}, y1 = {x2, x3}, y2 = {x0 + 4.f, x1 + 4.f}, y3 = {x2 + 4.f, x3 + 4.f}, pa = {va, va}, pb = {vb, vb};
+    for (int i = 0; i < iters; ++i) {
+#define PSTEP(ASM) REP32(asm volatile(ASM : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3) : "v"(pa), "v"(pb));)
+      if constexpr (FORM == 16) { PSTEP("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5") }
+      if constexpr (FORM == 17) { PSTEP("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4") }
+      if constexpr (FORM == 18) { PSTEP("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4") }
+    }
+    x0 = y0.x + y1.x + y2.x + y3.x; x1 = y0.y + y1.y + y2.y + y3.y;
+  }
   if (x0 + x1 + x2 + x3 == 123.456f) out[threadIdx.x] = x0;
 }
 
@@ -74,5 +85,8 @@ int main() {
   ROW(8, "v_cndmask_b32 v, v, v, s[n:n+1] (VOP3, SGPR pair)")
   ROW(12, "v_mov_b32_dpp wave_shr:1      (DPP)")
   ROW(13, "v_rcp_f32 v, v                (transcendental)")
+  ROW(16, "v_pk_fma_f32 v[2], v[2], v[2], v[2]  (two floats each)")
+  ROW(17, "v_pk_add_f32 v[2], v[2], v[2]        (two floats each)")
+  ROW(18, "v_pk_mul_f32 v[2], v[2], v[2]        (two floats each)")
   return 0;
 }
