@@ -49,6 +49,10 @@ HBM_PEAK_GBS = 8000.0    # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 # vector issue roof: 256 CUs x 4 SIMDs, a SIMD issues one wave64 VALU instruction per 2 cycles (SIMD-32), 2.4 GHz
 VALU_PEAK_WAVE_INSTS = 256 * 4 * 0.5 * 2.4e9
 FP32_PEAK_TFLOPS = 157.3  # = that rate x 64 lanes x 2 flop (every slot an FMA), same guide
+# what a stream of nothing but independent register-only v_fmac / v_add / v_mul sustains on this part, measured
+# (tools/valu_forms, profiles/r03_valu_issue_forms.log: 0.86-0.93e9 per second and SIMD at 2 or 4 waves per SIMD): reported
+# beside the spec-based fraction, never instead of it
+VALU_MEASURED_WAVE_INSTS = 256 * 4 * 0.90e9
 
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -314,6 +318,7 @@ def measure(name, world, rank, local_rank, steps, warmup):
                      "kernel": kernel, "steps_per_launch": tb, "what_binds_it": BINDS.get(family, ""),
                      "hbm_frac": round(hbm_frac, 4),
                      "valu_frac": None if valu_frac is None else round(valu_frac, 4),
+                     "valu_frac_of_measured_issue_rate": None if valu is None else round(valu / launch_s / VALU_MEASURED_WAVE_INSTS, 4),
                      "valu_wave_insts_per_launch": valu,
                      "valu_lane_insts_per_lattice_update": None if valu is None else round(valu * 64 / lups_per_launch, 1),
                      # the model figure: the bytes THIS kernel's blocking must move per update (kernel_of) at this
