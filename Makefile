@@ -23,7 +23,7 @@ all: $(EXE)
 
 lib: $(LIB)
 
-$(LIB): $(PKG)/csrc/lbm_api.hip $(PKG)/csrc/lbm_kernels.hip.h $(PKG)/csrc/lbm_exact_math.hip.h $(PKG)/csrc/lbm_march.hip.h $(PKG)/csrc/lbm_wave.hip.h $(PKG)/csrc/lbm_regtile.hip.h include/lbm_mi355x.h
+$(LIB): $(PKG)/csrc/lbm_api.hip $(PKG)/csrc/lbm_host_slabs.inc $(PKG)/csrc/lbm_host_march.inc $(PKG)/csrc/lbm_host_run.inc $(PKG)/csrc/lbm_kernels.hip.h $(PKG)/csrc/lbm_exact_math.hip.h $(PKG)/csrc/lbm_march.hip.h $(PKG)/csrc/lbm_wave.hip.h $(PKG)/csrc/lbm_regtile.hip.h include/lbm_mi355x.h
 	$(HIPCC) $(HIPFLAGS) -shared $< -o $@ -ldl -Wl,-rpath,/opt/rocm/lib
 
 $(EXE): $(PKG)/host/d2q9-bgk.c $(LIB) include/lbm_mi355x.h

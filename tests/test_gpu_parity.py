@@ -1654,7 +1654,7 @@ KERNEL_SELECTION = {
 
 
 def test_kernel_selection_table(gpu):
-    """the engine / kernel selection heuristics (lbm_api.hip: finish_create, plan_regtile, wave_pick_cols,
+    """VERDICT r02 next 8: the engine / kernel selection heuristics (csrc/lbm_host_slabs.inc: finish_create, wave_pick_cols; lbm_host_run.inc: plan_regtile;
     march_eligible, p2p_march_on, march_bands_on) over 31 (lattice, slab count, transport) points: which engine a run tries
     first, how many steps a pass fuses, which marching kernel, how many columns per lane.  No lattice is advanced."""
     import sys

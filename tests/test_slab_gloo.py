@@ -1,6 +1,6 @@
 """The row-slab decomposition and its halo protocol, rehearsed on CPU: world_size 2 and 3
 over gloo, one slab per rank, the oracle doing each slab's arithmetic.  What this pins is the
-PROTOCOL the HIP path implements natively (lbm_api.hip: which rows and planes travel, the
+PROTOCOL the HIP path implements natively (csrc/lbm_host_slabs.inc, lbm_host_march.inc: which rows and planes travel, the
 periodic ring, where the accelerate row lives, how av_vels is reduced); the HIP kernels and
 the RCCL transport themselves are covered by the -m gpu tests.
 
@@ -223,7 +223,7 @@ def _worker_march(rank, world, port, deck, ngroups, K, outdir):
 @pytest.mark.parametrize("world,deck,ngroups,K", [(2, "128x256", 6, 4), (2, "128x128", 6, 4), (3, "128x128", 4, 4), (2, "128x256", 3, 6), (2, "128x256", 3, 8), (3, "128x128", 2, 8)])
 def test_k_row_ghost_zone_of_the_marching_kernels(tmp_path, O, oracle, world, deck, ngroups, K):
     """K steps on a slab need K rows of each neighbour and nothing else (accelerate row included, wherever in the ghost
-    zone its periodic image falls): what lbm_march reads in place across slabs (lbm_api.hip: launch_march_slabs, run_p2p),
+    zone its periodic image falls): what lbm_march reads in place across slabs (csrc/lbm_host_march.inc: launch_march_slabs; lbm_host_run.inc: run_p2p),
     rehearsed with the oracle over gloo, NaN everywhere the algorithm does not compute."""
     import torch.multiprocessing as mp
     port = _free_port()
