@@ -61,7 +61,7 @@ def test_product_never_touches_the_oracle():
     pkg = os.path.join(ROOT, "advanced-hpc-lbm_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".c", ".h", ".hip", ".cpp")):
+            if f.endswith((".py", ".c", ".h", ".hip", ".cpp", ".inc")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "lbm_oracle" not in text and "liblbm_oracle" not in text, f
                 assert not re.search(r"^\s*(import|from)\s+oracle", text, flags=re.M), f
