@@ -345,7 +345,7 @@ __device__ __forceinline__ void regtile_body(const RegTileArgs& a) {
   for (int r = 0; r < R; ++r) {
     const long o = (long)(gy0 + r) * a.pitch + gx;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) q0[r][k] = a.src[k * a.plane + o];
+    for (int k = 0; k < 9; ++k) q0[r][k] = __builtin_nontemporal_load(&a.src[k * a.plane + o]);
     blk[r] = a.blocked[o] != 0;
   }
   auto first_state = [&](auto rc) {
@@ -599,11 +599,11 @@ __device__ __forceinline__ void regtile_body(const RegTileArgs& a) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const long o = (long)(gyq + r) * a.pitch + gxq;
-        if constexpr (OWN_LDS) { a.dst[o] = own[(r * 3 + 0) * 64]; a.dst[a.plane + o] = own[(r * 3 + 1) * 64]; a.dst[3 * a.plane + o] = own[(r * 3 + 2) * 64]; }
-        else { a.dst[o] = f[r][0]; a.dst[a.plane + o] = f[r][1]; a.dst[3 * a.plane + o] = f[r][3]; }
+        if constexpr (OWN_LDS) { __builtin_nontemporal_store(own[(r * 3 + 0) * 64], &a.dst[o]); __builtin_nontemporal_store(own[(r * 3 + 1) * 64], &a.dst[a.plane + o]); __builtin_nontemporal_store(own[(r * 3 + 2) * 64], &a.dst[3 * a.plane + o]); }
+        else { __builtin_nontemporal_store(f[r][0], &a.dst[o]); __builtin_nontemporal_store(f[r][1], &a.dst[a.plane + o]); __builtin_nontemporal_store(f[r][3], &a.dst[3 * a.plane + o]); }
 #pragma unroll
         for (int k = 2; k < 9; ++k)
-          if (k != 3) a.dst[k * a.plane + o] = f[r][k];
+          if (k != 3) __builtin_nontemporal_store(f[r][k], &a.dst[k * a.plane + o]);
       }
     }
     if (tid < 64) {
@@ -752,11 +752,11 @@ __device__ __forceinline__ void regtile_body(const RegTileArgs& a) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const long o = (long)(gyq + r) * a.pitch + gxq;
-      if constexpr (OWN_LDS) { a.dst[o] = own[(r * 3 + 0) * 64]; a.dst[a.plane + o] = own[(r * 3 + 1) * 64]; a.dst[3 * a.plane + o] = own[(r * 3 + 2) * 64]; }
-      else { a.dst[o] = f[r][0]; a.dst[a.plane + o] = f[r][1]; a.dst[3 * a.plane + o] = f[r][3]; }
+      if constexpr (OWN_LDS) { __builtin_nontemporal_store(own[(r * 3 + 0) * 64], &a.dst[o]); __builtin_nontemporal_store(own[(r * 3 + 1) * 64], &a.dst[a.plane + o]); __builtin_nontemporal_store(own[(r * 3 + 2) * 64], &a.dst[3 * a.plane + o]); }
+      else { __builtin_nontemporal_store(f[r][0], &a.dst[o]); __builtin_nontemporal_store(f[r][1], &a.dst[a.plane + o]); __builtin_nontemporal_store(f[r][3], &a.dst[3 * a.plane + o]); }
 #pragma unroll
       for (int k = 2; k < 9; ++k)
-        if (k != 3) a.dst[k * a.plane + o] = f[r][k];
+        if (k != 3) __builtin_nontemporal_store(f[r][k], &a.dst[k * a.plane + o]);
     }
   }
   if (tid < 64) {
