@@ -265,6 +265,10 @@ def test_two_step_halo_protocol_matches_single_domain_oracle(tmp_path, O, oracle
 
 @pytest.mark.parametrize("world,deck,nsteps", [(2, "128x256", 40), (2, "128x128", 40), (3, "128x128", 25)])
 def test_slab_protocol_matches_single_domain_oracle(tmp_path, O, oracle, world, deck, nsteps):
+    """One step per exchange: each rank sends planes 4,7,8 of its row 0 south and planes 2,5,6 of its top row north
+    (d2q9-bgk.c:971-998), everything else in the halo rows is NaN.  This is the message content of the one-step halo
+    kernels AND of the register tiles across slabs (csrc/lbm_regtile.hip.h, kRegSlab: the same three populations per column
+    and step, as 16-byte granules stored into the neighbour's mailboxes) -- only the transport differs."""
     import torch.multiprocessing as mp
     port = _free_port()
     mp.start_processes(_worker, args=(world, port, deck_paths(deck), nsteps, str(tmp_path)),
