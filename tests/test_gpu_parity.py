@@ -13,6 +13,7 @@ Bit-exact where the arithmetic is the same: repeatability, split runs, slab deco
 x-translations (all are the same per-cell float operations in a different launch geometry)."""
 import os
 import subprocess
+import sys
 import time
 
 import numpy as np
@@ -1441,6 +1442,21 @@ def test_register_tile_asynchronous_loop_equals_single_step_kernel(gpu, tile, nx
 # (nx, ny, slabs on one GPU, transport) -> (engine the next run tries first: 3 = lbm_regtile, 1 = streaming kernels;
 #  steps per pass; 1 = lbm_wave rather than lbm_march; columns per lane of lbm_wave).  Written by tools/selection_table.py on an
 # MI355X (256 CUs); "rccl" = one rank of a RCCL job as a ring of one.
+def test_largest_lattice_16384_squared(gpu):
+    """The maximum-size edge case: 16384 x 16384 (19 GB of lattices, plane offsets beyond 32-bit bytes), through
+    tools/big_lattice_check.py -- x-translation invariance bit for bit, the default kernel (lbm_wave<8>, two columns per lane)
+    against the one-step kernel over 19 steps (two passes, a pair, a single step) bit for bit, mass drift."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "big_lattice_check.py")], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, GRAFT_REPO_ROOT=ROOT))
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout
+    assert "translation invariance bit-exact: True av close: True" in out
+    assert "two-step == one-step bit-exact: True" in out
+    assert "default (8 steps per pass) == one-step bit-exact over 19 steps: True av close: True" in out
+    drift = float(out.split("mass drift")[1].split()[0])
+    assert drift < 2e-6
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Register tiles ACROSS SLABS (VERDICT r02 next 7; SURVEY 8 f1, the multi-GPU half): every slab's rows stay in the registers
 # of its GPU, the granules that leave a slab go straight into the neighbouring slab's mailboxes.
