@@ -1442,6 +1442,21 @@ def test_register_tile_asynchronous_loop_equals_single_step_kernel(gpu, tile, nx
 # (nx, ny, slabs on one GPU, transport) -> (engine the next run tries first: 3 = lbm_regtile, 1 = streaming kernels;
 #  steps per pass; 1 = lbm_wave rather than lbm_march; columns per lane of lbm_wave).  Written by tools/selection_table.py on an
 # MI355X (256 CUs); "rccl" = one rank of a RCCL job as a ring of one.
+def test_register_tiling_on_the_device_is_the_planned_one(gpu):
+    """lbm_plan_tiles (host arithmetic, pinned on CPU by tests/test_abi.py) against what contexts on the device report."""
+    L = gpu
+    with L.Lattice(L.Param(64, 64, 1, 1, 0.1, 0.01, 1.85), np.zeros((64, 64), dtype=np.int32)) as lat:
+        ncu = int(lat.info("compute_units"))
+    for nx, ny, nslabs in ((1024, 1024, 1), (256, 256, 1), (128, 256, 1), (64, 8, 1), (1024, 1024, 2), (1024, 1024, 8), (256, 256, 4), (1024, 128, 1)):
+        p = L.Param(nx, ny, 1, 1, 0.1, 0.01, 1.85)
+        ob = np.zeros((ny, nx), dtype=np.int32)
+        kw = dict(nslabs=nslabs, devices=[0] * nslabs, exchange=L.EXCHANGE_P2P) if nslabs > 1 else {}
+        with L.Lattice(p, ob, **kw) as lat:
+            want = L.plan_tiles(nx, ny // nslabs, slabs_per_device=nslabs, compute_units=ncu)
+            assert want is not None and int(lat.info("regtile")) == want[0] * 10 + want[1], (nx, ny, nslabs, want, lat.info("regtile"))
+            assert lat.info("engine_next") == 3
+
+
 def test_largest_lattice_16384_squared(gpu):
     """The maximum-size edge case: 16384 x 16384 (19 GB of lattices, plane offsets beyond 32-bit bytes), through
     tools/big_lattice_check.py -- x-translation invariance bit for bit, the default kernel (lbm_wave<8>, two columns per lane)
