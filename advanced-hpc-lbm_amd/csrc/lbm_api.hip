@@ -970,6 +970,11 @@ extern "C" int lbm_set_option(lbm_ctx* c, const char* key, long value) {
     }
     return LBM_OK;
   }
+  if (!strcmp(key, "regtile_tag")) {      // test hook: the next mailbox tag (they only grow: tests reach the restart paths with it)
+    if (value < (long)c->rtag || value >= 0x7fffff00L) return fail(LBM_EINVAL, "regtile_tag must not go back (now %u) and must stay below 2^31", c->rtag);
+    c->rtag = (uint32_t)value;
+    return LBM_OK;
+  }
   if (!strcmp(key, "regtile_async")) {
     if (value != 0 && value != 1) return fail(LBM_EINVAL, "regtile_async must be 0 or 1");
     c->regtile_async = (int)value;
@@ -1025,6 +1030,7 @@ extern "C" int lbm_get_info(const lbm_ctx* c, const char* key, double* value) {
   if (!strcmp(key, "compute_units")) { *value = c->ncu; return LBM_OK; }
   if (!strcmp(key, "regtile")) { *value = c->exchange != 0 ? c->splan.ty * 10.0 + c->splan.r : c->tplan.ty * 10.0 + c->tplan.r; return LBM_OK; }
   if (!strcmp(key, "regtile_async")) { *value = c->regtile_async; return LBM_OK; }
+  if (!strcmp(key, "regtile_tag")) { *value = c->rtag; return LBM_OK; }
   if (!strcmp(key, "exchange")) { *value = c->exchange; return LBM_OK; }
   if (!strcmp(key, "pitch")) { *value = c->slabs[0].pitch; return LBM_OK; }
   if (!strcmp(key, "hbm_bytes")) {

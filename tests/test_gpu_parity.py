@@ -1442,6 +1442,31 @@ def test_register_tile_asynchronous_loop_equals_single_step_kernel(gpu, tile, nx
 # (nx, ny, slabs on one GPU, transport) -> (engine the next run tries first: 3 = lbm_regtile, 1 = streaming kernels;
 #  steps per pass; 1 = lbm_wave rather than lbm_march; columns per lane of lbm_wave).  Written by tools/selection_table.py on an
 # MI355X (256 CUs); "rccl" = one rank of a RCCL job as a ring of one.
+@pytest.mark.parametrize("nslabs", [1, 4])
+def test_mailbox_tags_start_over_before_they_wrap(gpu, nslabs):
+    """The granules' tags are 31-bit step counters of the context.  A lattice alone clears its mailboxes and starts over in
+    front of the run that would wrap them; slabs clear at the END of the run that passes 0x60000000 (behind their launch, in
+    front of the closing all-reduce, so that no early mail of the next run is wiped).  Test hook: option regtile_tag."""
+    L = gpu
+    p, ob, cells = _random_case(L, 128, 128, 9)
+    with L.Lattice(p, ob, cells) as lat:
+        lat.set_option("time_block", 1)
+        av1 = np.concatenate([lat.run(n) for n in (300, 7, 40)])
+        st1 = lat.read_state()
+    kw = dict(nslabs=nslabs, devices=[0] * nslabs, exchange=L.EXCHANGE_P2P) if nslabs > 1 else {}
+    with L.Lattice(p, ob, cells, **kw) as lat:
+        lat.set_option("regtile_tag", 0x60000000 - 100 if nslabs > 1 else 0x7fffff00 - 310)
+        av2 = [lat.run(300)]                        # slabs: passes the mark -> cleared behind it; alone: still fits
+        t_mid = int(lat.info("regtile_tag"))
+        av2.append(lat.run(7))                      # alone: this one would wrap -> cleared in front of it
+        av2.append(lat.run(40))
+        assert lat.info("engine_last") == 3 and lat.info("resident_fallback") == 0
+        assert int(lat.info("regtile_tag")) < 1000 and (t_mid == 1 if nslabs > 1 else t_mid > 0x7ffffe00)
+        st2 = lat.read_state()
+    assert np.array_equal(st1.view(np.uint32), st2.view(np.uint32))
+    assert np.allclose(av1, np.concatenate(av2), rtol=2e-6, atol=0)
+
+
 def test_register_tiling_on_the_device_is_the_planned_one(gpu):
     """lbm_plan_tiles (host arithmetic, pinned on CPU by tests/test_abi.py) against what contexts on the device report."""
     L = gpu
