@@ -190,7 +190,7 @@ int lbm_plan_tiles(int nx, int rows, int slabs_per_device, int compute_units, in
 /* Tuning / introspection (never needed for correctness; the table of keys is INTEGRATION.md section 3).
  * Options: "engine" (0 auto, 1 streaming kernels, 3 register tiles -- alone or across slabs -- or fail), "time_block"
  * (1, 2, 4, 6, 8 steps per pass), "march_kernel", "march_rows", "wave_rows", "wave_cols" (1, 2), "regtile" (tiling),
- * "regtile_async" (0, 1), "kernel_variant" (bits: 1 fast rcp / sqrt, 2 / 4 nontemporal stores / loads, 8 the reference's
+ * "regtile_async" (0, 1), "regtile_tag" (test hook: the next mailbox tag), "kernel_variant" (bits: 1 fast rcp / sqrt, 2 / 4 nontemporal stores / loads, 8 the reference's
  * form of the speed sum, d2q9-bgk.c:1783-1811, 256 one-step kernel only), "vector_width", "t2_threads".
  * Info: "engine_last", "engine_next", "resident_fallback", "time_block_active", "march_kernel", "wave_rows",
  * "wave_cols_active", "wave_out_cols", "regtile", "regtile_blocks_per_cu", "exchange", "compute_units", "fluid_cells",
