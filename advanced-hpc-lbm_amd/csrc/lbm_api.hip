@@ -239,6 +239,7 @@ struct lbm_ctx {
   char resident_why[160] = "";    // ... and why (lbm_last_error does not carry it: the run itself succeeds)
   // register tiles across slabs: the same 64 x ty tiling on every slab (ty == 0: none); nty = tile rows per slab
   struct { int ty = 0, r = 0, nw = 0, ntx = 0, nty = 0, bpc = 0; } splan;
+  bool splan_peers = false;             // peer access between the neighbouring slabs' devices has been switched on
   lbm::RegTileArgs* rtable = nullptr;   // pinned, device-mapped: one entry per local slab, grouped by device
   lbm::RegTileArgs* rtable_dev = nullptr;
   int ncu = 0;                 // CUs of slab 0's device
